@@ -1,0 +1,200 @@
+/*
+ * vsx.h — C ABI of libvsx.so, the MI355X (gfx950) denoising-path kernels for VideoSwap.
+ *
+ * This is the drop-in boundary of the hot path: the Python host classes in
+ * videoswap_amd/ (same names and call signatures as the reference's UNet / Attention / pipeline
+ * classes) bind exactly these entry points through ctypes.  Nothing here takes a torch type:
+ * plain device pointers, sizes, element strides and the hipStream_t to launch on.
+ *
+ * Contract (all entry points):
+ *   - every tensor is fp16 (IEEE binary16) in device memory unless stated; accumulation is fp32;
+ *   - the CALLER owns all memory (inputs, outputs, workspaces); the library never allocates or
+ *     frees device memory and never synchronises; every call is asynchronous on `stream`;
+ *   - return 0 (VSX_OK) on success, a negative VSX_E_* code otherwise; vsx_last_error() returns a
+ *     thread-local description of the last failure; no exception crosses the ABI;
+ *   - pointers must be 16-byte aligned and row strides multiples of 8 elements (16-byte vector
+ *     access) unless a function says otherwise; violations return VSX_E_BADSHAPE;
+ *   - activations are channels-last: a video tensor the reference holds as [B,C,F,H,W]
+ *     (reference videoswap/models/animatediff_models/resnet.py:12-16) lives here as
+ *     [B*F, H, W, C] == token matrix [B*F*H*W, C].
+ *
+ * Each entry point cites the reference call site it replaces (file:line into showlab/VideoSwap).
+ */
+#ifndef VSX_H_
+#define VSX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSX_ABI_VERSION 1
+
+#define VSX_OK 0
+#define VSX_E_BADSHAPE (-1)
+#define VSX_E_UNSUPPORTED (-2)
+#define VSX_E_LAUNCH (-3)
+#define VSX_E_WORKSPACE (-4)
+
+typedef void* vsx_stream_t; /* hipStream_t */
+
+int vsx_abi_version(void);
+const char* vsx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1/K2: MFMA GEMM / implicit-GEMM convolution with fused epilogues.
+ *   C[z][m, n] = epilogue( alpha * sum_k A[z][m, k] * B[z][n, k] )        (both operands K-major)
+ * Replaces: nn.Linear / 1x1 nn.Conv2d (attention.py:65,93; motion_module.py:113,136; diffusers
+ * Attention.to_q/k/v/out, FeedForward), InflatedConv3d 3x3 (resnet.py:9-18), Downsample3D
+ * (resnet.py:83), Upsample3D nearest-2x + conv (resnet.py:54,66), the channel concat of the up
+ * blocks (unet_blocks.py:618,720), torch.baddbmm/bmm of get_attention_scores / probs @ V
+ * (attention_register.py:70-76,150-156).
+ * All integer fields are 64-bit so the struct has no padding on any ABI.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vsx_gemm_desc {
+    int64_t M, N, K;     /* N = output columns (for geglu: N = K_out = half of B's rows) */
+    int64_t batch0, batch1; /* grid.z = batch0*batch1; z0 = z / batch1, z1 = z % batch1 */
+
+    /* A operand */
+    const void* A;       /* a_mode 0: [M,K] row-major, row stride lda; a_mode 1: NHWC image(s) */
+    const void* A2;      /* a_mode 1 only: second source concatenated on C (may be NULL) */
+    int64_t lda, a_bs0, a_bs1;
+    int64_t a_mode;      /* 0 = plain rows, 1 = implicit im2col of a ks x ks conv, pad ks/2 */
+    int64_t H, W;        /* a_mode 1: logical input height/width (after the optional 2x upsample) */
+    int64_t C1, C2;      /* a_mode 1: channels of A and A2 (C2 = 0 without A2); K = ks*ks*(C1+C2) */
+    int64_t ks, stride;  /* a_mode 1: kernel size 1 or 3, stride 1 or 2 */
+    int64_t upsample;    /* a_mode 1: 1 = A/A2 are [.., H/2, W/2, C], read as nearest-2x upsampled */
+
+    /* B operand: [N (or 2N for geglu), K] row-major (PyTorch Linear weight / OHWI conv weight) */
+    const void* B;
+    int64_t ldb, b_bs0, b_bs1;
+
+    /* C */
+    void* C;
+    int64_t ldc, c_bs0, c_bs1;
+    int64_t c_mode;         /* 0: C[m*ldc+n]; 1: transposed per image: C[img*c_img_stride + n*ldc + m%rows] */
+    int64_t c_rows_per_img; /* c_mode 1: rows (tokens) per image */
+    int64_t c_img_stride;   /* c_mode 1: element stride between images */
+
+    /* epilogue */
+    const void* bias;     /* [N] (geglu: [2N]) or NULL */
+    const void* rowvec;   /* [ceil(M/rows_per_vec), N] added to row m from row m/rows_per_vec, or NULL
+                             (time-embedding broadcast, resnet.py:172-176) */
+    int64_t rows_per_vec;
+    const void* residual; /* [M,N] with row stride ldr added after everything else, or NULL */
+    int64_t ldr, r_bs0, r_bs1;
+    int64_t geglu;        /* 1: out[m,n] = (acc_h+b_h) * gelu_erf(acc_g+b_g), h=row n, g=row N+n of B
+                             (diffusers GEGLU used at attention.py:204, motion_module.py:218) */
+    double alpha;
+} vsx_gemm_desc;
+
+int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3: GroupNorm over channels-last activations, two kernels.
+ *   x = concat_C(x1[nimg, rows, C1], x2[nimg, rows, C2]); statistics per (img, group) over
+ *   rows x (C/groups).  nimg = B and rows = F*H*W reproduces the reference's 5-D GroupNorm
+ *   (resnet.py:166,177; unet.py:474: statistics pooled over frames); nimg = B*F, rows = H*W the
+ *   per-frame one (attention.py:108; motion_module.py:146).
+ * vsx_groupnorm_stats writes fp32 partial sums partial[img][chunk][group][2] (sum, sumsq) with
+ * chunk count = vsx_groupnorm_chunks(rows); vsx_groupnorm_apply reduces them (deterministic
+ * order) and writes y = (x-mean)*rstd*gamma+beta (optionally SiLU) as one [nimg, rows, C1+C2].
+ * In frame-sharded mode the caller all-reduces `partial` between the two calls and passes the
+ * GLOBAL element count in `count_rows`.
+ * ------------------------------------------------------------------------------------------ */
+int64_t vsx_groupnorm_chunks(int64_t rows);
+int vsx_groupnorm_stats(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
+                        int64_t C2, int64_t groups, float* partial, vsx_stream_t stream);
+int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
+                        int64_t C2, int64_t groups, const float* partial, int64_t nchunks,
+                        int64_t count_rows, const void* gamma, const void* beta, float eps,
+                        int64_t silu, void* y, vsx_stream_t stream);
+
+/* K4: LayerNorm over the last dim of x[M, C] (attention.py:182,199,205; motion_module.py:213,219).
+ * If pe != NULL, adds pe[((m / rows_per_frame) % frames) + frame_offset][c] (fp16 [max_len, C]) to
+ * the normalised row: the AnimateDiff temporal positional encoding (motion_module.py:253-255,
+ * 291-292) fused so that no '(b f) d c -> (b d) f c' copy is needed. */
+int vsx_layernorm(const void* x, int64_t M, int64_t C, const void* gamma, const void* beta,
+                  float eps, const void* pe, int64_t rows_per_frame, int64_t frames,
+                  int64_t frame_offset, void* y, vsx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5/K6: fused attention O = softmax(Q K^T * scale) V, online softmax, MFMA, never
+ * materialising the scores.  Replaces F.scaled_dot_product_attention (diffusers AttnProcessor2_0,
+ * the default processor of attention.py:174-194) and xformers.memory_efficient_attention
+ * (edlora_util.py:61; attention_register.py:67,147).
+ *   Q  [nb, nq, heads*d]  row stride ldq     K [nkvb, nk, heads*d] row stride ldk
+ *   VT [nkvb, heads*d, ldvt] = V transposed per image (written by vsx_gemm_f16 c_mode 1);
+ *       ldvt >= round_up(nk, 8)
+ *   O  [nb, nq, heads*d]  row stride ldo
+ * image b uses K/V image b / kv_div (kv_div = frames for cross-attention where the text
+ * embedding is shared by all frames: the reference repeats it, attention.py:100-103).
+ * d in {8,16,32,40,64,80,128,160}.
+ * ------------------------------------------------------------------------------------------ */
+int vsx_attention_f16(const void* Q, const void* K, const void* VT, void* O, int64_t nb,
+                      int64_t heads, int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk,
+                      int64_t ldvt, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t vt_bs,
+                      int64_t o_bs, int64_t kv_div, float scale, vsx_stream_t stream);
+
+/* K7 helper: in-place row softmax of fp16 scores S[nrows, ld] over the first ncols columns
+ * (diffusers Attention.get_attention_scores softmax; probs are then handed to the
+ * Prompt-to-Prompt controller, attention_register.py:70-76). */
+int vsx_softmax_rows(void* S, int64_t nrows, int64_t ncols, int64_t ld, vsx_stream_t stream);
+
+/* K8: temporal self-attention across frames at every spatial site (motion_module.py:287-338),
+ * computed directly on the [B, F, HW, heads*d] layout (no transposes).  q/k/v/o share row
+ * stride ld.  In frame-sharded mode q holds the local fq frames and k/v the gathered fk frames. */
+int vsx_temporal_attention_f16(const void* Q, const void* K, const void* V, void* O, int64_t B,
+                               int64_t fq, int64_t fk, int64_t hw, int64_t heads, int64_t d,
+                               int64_t ldq, int64_t ldkv, int64_t ldo, float scale,
+                               vsx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K11: element-wise glue.
+ * ------------------------------------------------------------------------------------------ */
+/* y = silu(x) (resnet.py:172: nonlinearity(temb)) ; n elements */
+int vsx_silu(const void* x, void* y, int64_t n, vsx_stream_t stream);
+/* y = a + s*b (adapter residual add, unet_blocks.py:399-402; unet.py:434-438) */
+int vsx_axpy(const void* a, const void* b, float s, void* y, int64_t n, vsx_stream_t stream);
+/* Latent layout conversion at the UNet boundary.
+ * pack:   x[B,Cin,F,H,W] -> y[B*F,H,W,Cpad] (channels >= Cin zero-filled), unet.py:411
+ * unpack: x[B*F,H,W,Cs] (first Cout channels) -> y[B,Cout,F,H,W], unet.py:476 */
+int vsx_pack_latents(const void* x, void* y, int64_t B, int64_t Cin, int64_t F, int64_t HW,
+                     int64_t Cpad, vsx_stream_t stream);
+int vsx_unpack_latents(const void* x, void* y, int64_t B, int64_t Cout, int64_t F, int64_t HW,
+                       int64_t Cs, vsx_stream_t stream);
+/* Classifier-free guidance + DDIM update in one pass (pipeline_videoswap.py:578-580,587 and the
+ * diffusers DDIMScheduler.step / DDIMInverseScheduler.step arithmetic, eta = 0):
+ *   eps = eps_u + g*(eps_c - eps_u)   (eps_c == NULL: eps = eps_u)
+ *   x0  = (x - sqrt(1-a_t) eps)/sqrt(a_t);  out = sqrt(a_n) x0 + sqrt(1-a_n) eps
+ * with fp32 arithmetic, fp16 storage. */
+int vsx_cfg_ddim_step(const void* x, const void* eps_u, const void* eps_c, float guidance,
+                      float alpha_t, float alpha_next, void* out, int64_t n, vsx_stream_t stream);
+/* Latent blend of the Prompt-to-Prompt SpatialBlender (spatial_blend.py:142):
+ * out = src + mask*(x - src); mask fp16 broadcast over channels: x,src [C, n_sp], mask [n_sp]. */
+int vsx_masked_blend(const void* x, const void* src, const void* mask, void* out, int64_t C,
+                     int64_t n_sp, vsx_stream_t stream);
+
+/* K10: SparsePointAdapter scatter (adapter_model.py:25-47,112-131): for every visible point p in
+ * frame f splat feat[p,:]*w onto the 4 bilinear corners (clamped to the edge, accumulating) of
+ * out[f, y, x, :] (channels-last, fp16, must be zero-filled by the caller).
+ * tracks [F,P,2] fp32 pixel coords (x,y); negative = invisible; selected[P] int32 0/1. */
+int vsx_adapter_scatter(const float* tracks, const int32_t* selected, const void* feat, void* out,
+                        int64_t F, int64_t P, int64_t C, int64_t h, int64_t w, float rate,
+                        float out_scale, vsx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Launch-time instrumentation used by bench.py: when enabled, vsx_gemm_f16 brackets each of its
+ * launches with hipEvents on the launch stream (at most `max_samples` launches are sampled).
+ * vsx_prof_collect synchronises those events and returns the number of sampled launches, their
+ * summed duration (ms) and summed algorithmic FLOP (2*M*N*K*batch; geglu counts B's 2N rows).
+ * ------------------------------------------------------------------------------------------ */
+int vsx_prof_enable(int64_t on, int64_t max_samples);
+int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* total_flop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSX_H_ */

@@ -1,0 +1,328 @@
+"""GPU parity tests of every libvsx kernel against a plain PyTorch fp32 reference of the same op.
+
+Inputs are fp16 (exactly representable in the fp32 reference), so the only differences are the
+accumulation order and the final fp16 rounding: tolerances are a few fp16 ulps of the output scale.
+All calls go through the C ABI (videoswap_amd.ops -> ctypes -> libvsx.so).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def ops():
+    from videoswap_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(torch.float16).to(DEV)
+
+
+def rel_err(out, ref):
+    out = out.float()
+    ref = ref.float()
+    assert out.shape == ref.shape, f'shape {tuple(out.shape)} vs {tuple(ref.shape)}'
+    assert torch.isfinite(out).all(), 'non-finite values in kernel output'
+    return ((out - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+
+
+# --------------------------------------------------------------------------------------------
+# GEMM
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(256, 256, 128), (300, 200, 72), (1024, 320, 320), (2, 1280, 320),
+                                   (8192, 1280, 640), (77, 64, 768), (131, 40, 8)])
+def test_linear(M, N, K):
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    out = ops().linear(x, w, b, residual=r)
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    assert rel_err(out, ref) < 2e-3
+    out2 = ops().linear(x, w)
+    assert rel_err(out2, x.float() @ w.float().t()) < 2e-3
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 256, 128), (100, 72, 64), (8192, 1280, 320)])
+def test_linear_geglu(M, N, K):
+    x, w, b = rnd(M, K, seed=5), rnd(2 * N, K, seed=6, scale=K ** -0.5), rnd(2 * N, seed=7)
+    out = ops().linear(x, w, b, geglu=True)
+    y = x.float() @ w.float().t() + b.float()
+    ref = y[:, :N] * F.gelu(y[:, N:])
+    assert out.shape == (M, N)
+    assert rel_err(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize('rows,nimg,N,K', [(64, 6, 64, 128), (77, 2, 320, 768), (256, 3, 40, 64)])
+def test_linear_vt(rows, nimg, N, K):
+    x, w, b = rnd(nimg * rows, K, seed=8), rnd(N, K, seed=9, scale=K ** -0.5), rnd(N, seed=10)
+    vt = ops().linear_vt(x, w, b, rows)
+    ref = (x.float() @ w.float().t() + b.float()).view(nimg, rows, N).transpose(1, 2)
+    assert vt.shape[2] % 8 == 0
+    assert rel_err(vt[:, :, :rows], ref) < 2e-3
+    if vt.shape[2] != rows:
+        assert (vt[:, :, rows:] == 0).all()
+
+
+def conv_ref(x, w, b, stride, x2=None, upsample=False):
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
+    xin = xin.permute(0, 3, 1, 2)
+    if upsample:
+        xin = F.interpolate(xin, scale_factor=2.0, mode='nearest')
+    ks = w.shape[1]
+    wt = w.float().permute(0, 3, 1, 2)
+    y = F.conv2d(xin, wt, b.float() if b is not None else None, stride=stride, padding=ks // 2)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize('nimg,H,W,C1,C2,Cout,ks,stride,ups', [
+    (2, 16, 16, 64, 0, 64, 3, 1, False),
+    (3, 12, 20, 8, 0, 32, 3, 1, False),      # conv_in-like (Cin padded to 8), non-square
+    (2, 16, 16, 64, 0, 128, 3, 2, False),    # Downsample3D
+    (2, 8, 12, 64, 0, 64, 3, 1, True),       # Upsample3D (nearest 2x folded into the loader)
+    (2, 16, 16, 128, 64, 64, 3, 1, False),   # skip concat folded into the loader
+    (2, 16, 16, 128, 64, 96, 1, 1, False),   # 1x1 shortcut on a concat
+    (4, 64, 64, 320, 0, 320, 3, 1, False),   # big-tile path
+    (2, 14, 24, 320, 0, 4, 3, 1, False),     # conv_out-like (N = 4)
+])
+def test_conv2d(nimg, H, W, C1, C2, Cout, ks, stride, ups):
+    x = rnd(nimg, H, W, C1, seed=11)
+    x2 = rnd(nimg, H, W, C2, seed=12) if C2 else None
+    K = ks * ks * (C1 + C2)
+    w = rnd(Cout, ks, ks, C1 + C2, seed=13, scale=K ** -0.5)
+    b = rnd(Cout, seed=14)
+    out = ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups)
+    ref = conv_ref(x, w, b, stride, x2, ups)
+    assert rel_err(out, ref) < 2e-3
+
+
+def test_conv2d_epilogue_rowvec_residual():
+    nimg, H, W, C, Cout = 4, 8, 8, 64, 128
+    x, w, b = rnd(nimg, H, W, C, seed=15), rnd(Cout, 3, 3, C, seed=16, scale=(9 * C) ** -0.5), rnd(Cout, seed=17)
+    rowvec = rnd(2, Cout, seed=18)           # 2 "batches" of 2 frames
+    res = rnd(nimg, H, W, Cout, seed=19)
+    out = ops().conv2d(x, w, b, rowvec=rowvec, rows_per_vec=2 * H * W, residual=res)
+    ref = conv_ref(x, w, b, 1) + rowvec.float().repeat_interleave(2, 0)[:, None, None, :] + res.float()
+    assert rel_err(out, ref) < 2e-3
+
+
+# --------------------------------------------------------------------------------------------
+# normalisation
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('nimg,rows,C1,C2,groups,silu', [
+    (2, 4 * 64, 64, 0, 32, True),       # 5-D statistics: B=2, F*HW rows
+    (8, 64, 320, 0, 32, False),        # per-frame
+    (2, 1000, 640, 320, 32, True),     # concat, cpg = 30 (vector straddles groups)
+    (2, 700, 1280, 1280, 32, True),    # C = 2560
+    (3, 50, 32, 0, 8, False),
+])
+def test_group_norm(nimg, rows, C1, C2, groups, silu):
+    x = rnd(nimg, rows, C1, seed=20) + 0.5
+    x2 = rnd(nimg, rows, C2, seed=21) if C2 else None
+    C = C1 + C2
+    gamma, beta = rnd(C, seed=22) + 1.0, rnd(C, seed=23)
+    out = ops().group_norm(x, gamma, beta, groups, 1e-5, nimg, silu=silu, x2=x2)
+    xin = x.float() if x2 is None else torch.cat([x.float(), x2.float()], -1)
+    ref = F.group_norm(xin.transpose(1, 2), groups, gamma.float(), beta.float(), 1e-5).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_err(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize('M,C', [(1000, 320), (64, 1280), (7, 64), (33, 640)])
+def test_layer_norm(M, C):
+    x, g, b = rnd(M, C, seed=24) * 2 + 0.3, rnd(C, seed=25) + 1, rnd(C, seed=26)
+    out = ops().layer_norm(x, g, b, 1e-5)
+    ref = F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5)
+    assert rel_err(out, ref) < 2e-3
+
+
+def test_layer_norm_pe():
+    B, Fr, HW, C = 2, 4, 16, 64
+    x, g, b, pe = rnd(B * Fr * HW, C, seed=27), rnd(C, seed=28) + 1, rnd(C, seed=29), rnd(24, C, seed=30)
+    out = ops().layer_norm(x, g, b, 1e-5, pe=pe, rows_per_frame=HW, frames=Fr, frame_offset=2)
+    ref = F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5).view(B, Fr, HW, C)
+    ref = ref + pe.float()[2:2 + Fr][None, :, None, :]
+    assert rel_err(out, ref.reshape(-1, C)) < 2e-3
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+def attn_ref(q, k, v, heads, scale, kv_div=1):
+    nb, nq, C = q.shape
+    d = C // heads
+    qh = q.float().view(nb, nq, heads, d).transpose(1, 2)
+    kh = k.float().view(k.shape[0], -1, heads, d).transpose(1, 2).repeat_interleave(kv_div, 0)
+    vh = v.float().view(v.shape[0], -1, heads, d).transpose(1, 2).repeat_interleave(kv_div, 0)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1)
+    return (p @ vh).transpose(1, 2).reshape(nb, nq, C), p
+
+
+def make_vt(v):
+    """[nkvb, nk, C] -> V^T [nkvb, C, round_up(nk, 8)] (zero padded)"""
+    nkvb, nk, C = v.shape
+    ld = (nk + 7) // 8 * 8
+    vt = torch.zeros(nkvb, C, ld, dtype=v.dtype, device=v.device)
+    vt[:, :, :nk] = v.transpose(1, 2)
+    return vt
+
+
+@pytest.mark.parametrize('nb,heads,nq,nk,d', [
+    (2, 8, 256, 256, 40), (2, 8, 128, 128, 80), (2, 4, 64, 64, 160), (1, 2, 1024, 1024, 40),
+    (2, 8, 84, 84, 40), (1, 8, 336, 336, 80), (2, 2, 200, 200, 8), (2, 2, 64, 64, 16), (2, 2, 100, 130, 32),
+    (1, 2, 128, 192, 64), (1, 1, 64, 64, 128),
+])
+def test_attention_self(nb, heads, nq, nk, d):
+    C = heads * d
+    q, k, v = rnd(nb, nq, C, seed=31), rnd(nb, nk, C, seed=32), rnd(nb, nk, C, seed=33)
+    scale = d ** -0.5
+    out = ops().attention(q, k, make_vt(v), heads, scale)
+    ref, _ = attn_ref(q, k, v, heads, scale)
+    assert rel_err(out, ref) < 4e-3
+
+
+def test_attention_peaked_softmax():
+    # forces the online-softmax rescale: one key dominates late in the key sequence
+    nb, heads, nq, nk, d = 1, 2, 128, 256, 40
+    C = heads * d
+    q, k, v = rnd(nb, nq, C, seed=34), rnd(nb, nk, C, seed=35), rnd(nb, nk, C, seed=36)
+    k[:, 200] = q[:, 5] * 4.0
+    k[:, 70] = q[:, 9] * 3.0
+    scale = d ** -0.5
+    out = ops().attention(q, k, make_vt(v), heads, scale)
+    ref, _ = attn_ref(q, k, v, heads, scale)
+    assert rel_err(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize('frames,nq,d', [(4, 256, 40), (2, 64, 160), (3, 100, 80)])
+def test_attention_cross_text(frames, nq, d):
+    B, heads, nk = 2, 8, 77
+    C = heads * d
+    q = rnd(B * frames, nq, C, seed=37)
+    k, v = rnd(B, nk, C, seed=38), rnd(B, nk, C, seed=39)
+    scale = d ** -0.5
+    out = ops().attention(q, k, make_vt(v), heads, scale, kv_div=frames)
+    ref, _ = attn_ref(q, k, v, heads, scale, kv_div=frames)
+    assert rel_err(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize('nb,heads,nq,nk,d,kv_div', [(4, 8, 64, 64, 40, 1), (4, 8, 256, 77, 40, 2), (2, 2, 100, 100, 16, 1)])
+def test_attention_scores_and_pv(nb, heads, nq, nk, d, kv_div):
+    C = heads * d
+    q = rnd(nb, nq, C, seed=40)
+    k, v = rnd(nb // kv_div, nk, C, seed=41), rnd(nb // kv_div, nk, C, seed=42)
+    scale = d ** -0.5
+    probs = ops().attention_scores(q, k, heads, scale, kv_div=kv_div)
+    ref_out, ref_p = attn_ref(q, k, v, heads, scale, kv_div=kv_div)
+    assert probs.shape == ref_p.shape
+    assert rel_err(probs, ref_p) < 4e-3
+    out = ops().attention_pv(probs, make_vt(v), kv_div=kv_div)
+    assert rel_err(out, ref_out) < 4e-3
+    # an edited (non-view) probs tensor must work too
+    out2 = ops().attention_pv((probs * 1.0).contiguous(), make_vt(v), kv_div=kv_div)
+    assert rel_err(out2, ref_out) < 4e-3
+
+
+@pytest.mark.parametrize('B,fq,fk,hw,heads,d', [(2, 16, 16, 64, 8, 40), (1, 4, 4, 256, 8, 80), (2, 16, 16, 16, 8, 160),
+                                               (1, 4, 16, 30, 2, 8), (1, 24, 24, 10, 4, 16)])
+def test_temporal_attention(B, fq, fk, hw, heads, d):
+    C = heads * d
+    q, k, v = rnd(B * fq * hw, C, seed=43), rnd(B * fk * hw, C, seed=44), rnd(B * fk * hw, C, seed=45)
+    scale = d ** -0.5
+    out = ops().temporal_attention(q, k, v, B, fq, fk, hw, heads, scale)
+
+    def sites(t, f):  # (b f s) c -> (b s) f c
+        return t.float().view(B, f, hw, C).permute(0, 2, 1, 3).reshape(B * hw, f, C)
+    ref, _ = attn_ref(sites(q, fq), sites(k, fk), sites(v, fk), heads, scale)
+    ref = ref.view(B, hw, fq, C).permute(0, 2, 1, 3).reshape(B * fq * hw, C)
+    assert rel_err(out, ref) < 3e-3
+
+
+# --------------------------------------------------------------------------------------------
+# element-wise glue
+# --------------------------------------------------------------------------------------------
+def test_silu_axpy():
+    x, y = rnd(1000, 33, seed=46) * 3, rnd(1000, 33, seed=47)
+    assert rel_err(ops().silu(x), F.silu(x.float())) < 1e-3
+    assert rel_err(ops().axpy(x, y, 0.5), x.float() + 0.5 * y.float()) < 1e-3
+
+
+def test_pack_unpack_latents():
+    x = rnd(2, 4, 3, 6, 10, seed=48)
+    p = ops().pack_latents(x, 8)
+    ref = torch.zeros(6, 6, 10, 8, device=DEV)
+    ref[..., :4] = x.float().permute(0, 2, 3, 4, 1).reshape(6, 6, 10, 4)
+    assert torch.equal(p.float(), ref)
+    y = rnd(6, 6, 10, 8, seed=49)
+    u = ops().unpack_latents(y, 2, 4)
+    assert torch.equal(u, y[..., :4].view(2, 3, 6, 10, 4).permute(0, 4, 1, 2, 3))
+
+
+def test_cfg_ddim_step():
+    x, eu, ec = rnd(1, 4, 4, 16, 16, seed=50), rnd(1, 4, 4, 16, 16, seed=51), rnd(1, 4, 4, 16, 16, seed=52)
+    a_t, a_n, g = 0.37, 0.52, 7.5
+    out = ops().cfg_ddim_step(x, eu, ec, g, a_t, a_n)
+    e = eu.float() + g * (ec.float() - eu.float())
+    x0 = (x.float() - math.sqrt(1 - a_t) * e) / math.sqrt(a_t)
+    ref = math.sqrt(a_n) * x0 + math.sqrt(1 - a_n) * e
+    assert rel_err(out, ref) < 1e-3
+    out1 = ops().cfg_ddim_step(x, eu, None, 1.0, a_t, a_n)
+    x0 = (x.float() - math.sqrt(1 - a_t) * eu.float()) / math.sqrt(a_t)
+    assert rel_err(out1, math.sqrt(a_n) * x0 + math.sqrt(1 - a_n) * eu.float()) < 1e-3
+
+
+def test_masked_blend():
+    x, s = rnd(4, 3, 8, 8, seed=53), rnd(4, 3, 8, 8, seed=54)
+    m = (torch.rand(3, 8, 8, device=DEV) > 0.5).half()
+    out = ops().masked_blend(x, s, m)
+    assert rel_err(out, s.float() + m.float() * (x.float() - s.float())) < 1e-3
+
+
+def test_adapter_scatter():
+    Fr, P, C, h, w, rate = 3, 5, 64, 8, 12, 8.0
+    g = torch.Generator().manual_seed(55)
+    tracks = torch.rand(Fr, P, 2, generator=g) * torch.tensor([w * rate, h * rate])
+    tracks[0, 1] = -1.0                      # invisible
+    tracks[1, 2] = torch.tensor([w * rate - 0.5, h * rate - 0.5])  # clamps to the edge: corners coincide
+    tracks[2, 3] = torch.tensor([16.0, 24.0])  # exactly on the grid
+    tracks = tracks.half().float()
+    sel = torch.tensor([1, 1, 1, 1, 0], dtype=torch.int32)
+    feat = rnd(P, C, seed=56)
+    out = ops().adapter_scatter(tracks.to(DEV), sel.to(DEV), feat, h, w, rate)
+    ref = torch.zeros(Fr, h, w, C)
+    fc = feat.float().cpu()
+    for p in range(P):
+        if not sel[p]:
+            continue
+        for f in range(Fr):
+            px, py = tracks[f, p].tolist()
+            if px < 0 or py < 0:
+                continue
+            x, y = px / rate, py / rate
+            x1, y1 = int(x), int(y)
+            x2, y2 = x1 + 1, y1 + 1
+            xf, yf = x - x1, y - y1
+            x1, x2 = max(min(x1, w - 1), 0), max(min(x2, w - 1), 0)
+            y1, y2 = max(min(y1, h - 1), 0), max(min(y2, h - 1), 0)
+            ref[f, y1, x1] += fc[p] * (1 - xf) * (1 - yf)
+            ref[f, y1, x2] += fc[p] * xf * (1 - yf)
+            ref[f, y2, x1] += fc[p] * (1 - xf) * yf
+            ref[f, y2, x2] += fc[p] * xf * yf
+    assert rel_err(out.cpu(), ref) < 4e-3
+    # on-grid point: a single pixel carries exactly the feature vector
+    assert torch.equal(out[2, 3, 2].cpu(), feat[3].cpu()) or rel_err(out[2, 3, 2].cpu(), fc[3]) < 2e-3
+
+
+def test_errors_are_reported():
+    from videoswap_amd._lib import VsxError
+    x = rnd(16, 12, seed=57)  # K = 12 is not a multiple of 8
+    w = rnd(8, 12, seed=58)
+    with pytest.raises(VsxError):
+        ops().linear(x, w)
+    with pytest.raises(VsxError):
+        ops().linear(x.cpu(), w.cpu())

@@ -1,0 +1,95 @@
+"""ctypes binding of libvsx.so — the C ABI declared in include/vsx.h.
+
+The library is the product: if it is missing, importing this module raises (no PyTorch or CPU
+fallback exists on the hot path).  Build it with ``python -m videoswap_amd.build``.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so')
+
+VSX_ABI_VERSION = 1
+
+
+class VsxError(RuntimeError):
+    pass
+
+
+class GemmDesc(Structure):
+    """Mirror of ``struct vsx_gemm_desc`` (every field is 8 bytes)."""
+    _fields_ = [
+        ('M', c_int64), ('N', c_int64), ('K', c_int64),
+        ('batch0', c_int64), ('batch1', c_int64),
+        ('A', c_void_p), ('A2', c_void_p),
+        ('lda', c_int64), ('a_bs0', c_int64), ('a_bs1', c_int64),
+        ('a_mode', c_int64), ('H', c_int64), ('W', c_int64), ('C1', c_int64), ('C2', c_int64),
+        ('ks', c_int64), ('stride', c_int64), ('upsample', c_int64),
+        ('B', c_void_p), ('ldb', c_int64), ('b_bs0', c_int64), ('b_bs1', c_int64),
+        ('C', c_void_p), ('ldc', c_int64), ('c_bs0', c_int64), ('c_bs1', c_int64),
+        ('c_mode', c_int64), ('c_rows_per_img', c_int64), ('c_img_stride', c_int64),
+        ('bias', c_void_p), ('rowvec', c_void_p), ('rows_per_vec', c_int64),
+        ('residual', c_void_p), ('ldr', c_int64), ('r_bs0', c_int64), ('r_bs1', c_int64),
+        ('geglu', c_int64), ('alpha', c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol of include/vsx.h
+PROTOTYPES = {
+    'vsx_abi_version': (c_int, []),
+    'vsx_last_error': (c_char_p, []),
+    'vsx_gemm_f16': (c_int, [POINTER(GemmDesc), c_void_p]),
+    'vsx_groupnorm_chunks': (c_int64, [c_int64]),
+    'vsx_groupnorm_stats': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                    c_void_p]),
+    'vsx_groupnorm_apply': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                    c_int64, c_int64, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
+    'vsx_layernorm': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
+                              c_int64, c_void_p, c_void_p]),
+    'vsx_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 14 + [c_float, c_void_p]),
+    'vsx_softmax_rows': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    'vsx_temporal_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 9
+                                   + [c_float, c_void_p]),
+    'vsx_silu': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'vsx_axpy': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
+    'vsx_pack_latents': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    'vsx_unpack_latents': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    'vsx_cfg_ddim_step': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_int64,
+                                  c_void_p]),
+    'vsx_masked_blend': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'vsx_adapter_scatter': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                    c_int64, c_float, c_float, c_void_p]),
+    'vsx_prof_enable': (c_int, [c_int64, c_int64]),
+    'vsx_prof_collect': (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libvsx.so (once) and type every entry point.  Raises VsxError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VsxError(
+            f'{LIB_PATH} not found: the HIP extension is the only implementation of the denoising path; '
+            f'build it with `python -m videoswap_amd.build` (hipcc --offload-arch=gfx950).')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    ver = lib.vsx_abi_version()
+    if ver != VSX_ABI_VERSION:
+        raise VsxError(f'libvsx ABI version {ver} != expected {VSX_ABI_VERSION}; rebuild the extension')
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        lib = load()
+        msg = lib.vsx_last_error().decode(errors='replace')
+        raise VsxError(f'{what} failed with code {rc}: {msg}')

@@ -1,0 +1,70 @@
+"""Build libvsx.so (hand-written HIP kernels for gfx950) in-tree with hipcc.
+
+    python -m videoswap_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  The shared library lands in videoswap_amd/lib/
+(git-ignored, but it travels with the gpurun snapshot).
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+OBJDIR = os.path.join(LIBDIR, 'obj')
+LIB = os.path.join(LIBDIR, 'libvsx.so')
+SOURCES = ['api.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
+         '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-Wall', '-Wno-unused-function']
+
+
+def _digest():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)) + ['../../include/vsx.h']:
+        with open(os.path.join(CSRC, name), 'rb') as f:
+            h.update(name.encode() + b'\0' + f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    obj = os.path.join(OBJDIR, src + '.o')
+    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, 'libvsx.sha256')
+    digest = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        if verbose:
+            print(f'[vsx] {LIB} is up to date')
+        return LIB
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f'{HIPCC} not found: cannot build libvsx.so')
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    with open(stamp, 'w') as f:
+        f.write(digest)
+    if verbose:
+        print(f'[vsx] built {LIB}')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

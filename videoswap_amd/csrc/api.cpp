@@ -1,0 +1,25 @@
+// Host-side plumbing of libvsx: ABI version, thread-local error string, launch check.
+#include "common.h"
+
+#include <string.h>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+int vsx_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int vsx_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return VSX_OK;
+}
+
+extern "C" int vsx_abi_version(void) { return VSX_ABI_VERSION; }
+extern "C" const char* vsx_last_error(void) { return g_err; }

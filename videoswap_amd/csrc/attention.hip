@@ -1,0 +1,358 @@
+// K5/K6 — fused attention for gfx950: O = softmax(Q K^T * scale) V with online softmax on
+// v_mfma_f32_32x32x16_f16, scores never leave the register file.
+//
+// Work split: workgroup = 4 wave64 = 128 query rows of one (image, head); each wave owns 32
+// query rows and walks the keys in tiles of 64.  Both products are computed TRANSPOSED so that
+// every per-query quantity (running max m, running sum l, rescale factor) is lane-local:
+//
+//   S^T[key, q] = K[key, :] . Q[q, :]      A = K tile (LDS), B = Q fragments (registers)
+//   O^T[c,   q] = V^T[c, key] . P^T[key,q] A = V^T tile (LDS), B = P (registers, straight from S^T)
+//
+// In the 32x32 MFMA C/D layout a lane holds column q = lane&31 and 16 of the 32 rows, so the
+// lane pair (q, q+32) holds a full score column: row max / row sum are 15 local ops plus one
+// cross-lane exchange, and the exponentiated scores are already in B-operand position for the
+// second product (the k-slot -> key assignment of P is matched when V^T fragments are read).
+// V arrives pre-transposed per image (vsx_gemm_f16 c_mode 1 writes V^T while projecting), which
+// keeps every LDS fragment read a contiguous 8/16-byte access.
+//
+// LDS: K tile [64][DK*16+8] halfs (row = 2*DK+1 16-byte slots, odd => conflict-free b128 reads),
+//      V^T tile [DT*32][68] halfs (136-byte rows => conflict-free b64 reads).
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+    const half_t* Q;
+    const half_t* K;
+    const half_t* VT;
+    half_t* O;
+    int nq, nk, heads;
+    long ldq, ldk, ldvt, ldo;
+    long q_bs, k_bs, vt_bs, o_bs;
+    int kv_div;
+    float scale_log2e;
+};
+
+constexpr int KV_TILE = 64;
+constexpr int VSTR = 68;
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
+    constexpr int DK = (D + 15) / 16;   // k-steps of the QK^T product
+    constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T
+    constexpr int KSTR = DK * 16 + 8;
+
+    __shared__ __attribute__((aligned(16))) half_t sK[KV_TILE * KSTR];
+    __shared__ __attribute__((aligned(16))) half_t sV[DT * 32 * VSTR];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const long kvb = b / p.kv_div;
+
+    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const bool qok = q < p.nq;
+
+    // Q fragments: B operand of S^T = K Q^T; lane (q, hi) holds Q[q, t*16 + hi*8 .. +7]
+    h8 qf[DK];
+    {
+        const half_t* qrow = p.Q + b * p.q_bs + (long)(qok ? q : 0) * p.ldq + h * D;
+#pragma unroll
+        for (int t = 0; t < DK; ++t) {
+            const int d0 = t * 16 + hi * 8;
+            qf[t] = (qok && d0 < D) ? as_h8(ld16(qrow + d0)) : as_h8(make_uint4(0, 0, 0, 0));
+        }
+    }
+
+    f16v o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_i = -INFINITY;
+    float l_i = 0.f;
+
+    const half_t* Kb = p.K + kvb * p.k_bs + h * D;
+    const half_t* Vb = p.VT + kvb * p.vt_bs + (long)h * D * p.ldvt;
+
+    for (int j0 = 0; j0 < p.nk; j0 += KV_TILE) {
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K tile: 64 rows x DK*2 vectors ----
+        for (int i = tid; i < KV_TILE * DK * 2; i += 256) {
+            const int row = i / (DK * 2);
+            const int d0 = (i - row * (DK * 2)) * 8;
+            const int key = j0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (key < p.nk && d0 < D) v = ld16(Kb + (long)key * p.ldk + d0);
+            st16(sK + row * KSTR + d0, v);
+        }
+        // ---- stage V^T tile: DT*32 rows x 8 vectors of 8 keys ----
+        for (int i = tid; i < DT * 32 * 8; i += 256) {
+            const int row = i >> 3;
+            const int c8 = (i & 7) * 8;
+            const int key0 = j0 + c8;
+            h8 v = as_h8(make_uint4(0, 0, 0, 0));
+            if (row < D && key0 < p.nk) {
+                v = as_h8(ld16(Vb + (long)row * p.ldvt + key0));
+                if (key0 + 8 > p.nk) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (key0 + e >= p.nk) v[e] = (half_t)0.f;
+                }
+            }
+            const uint4 u = as_u4(v);
+            uint2* dst = reinterpret_cast<uint2*>(sV + row * VSTR + c8);
+            dst[0] = make_uint2(u.x, u.y);
+            dst[1] = make_uint2(u.z, u.w);
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T : two 32-key row tiles ----
+        f16v s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+            const half_t* krow = sK + (kt * 32 + l31) * KSTR + hi * 8;
+#pragma unroll
+            for (int t = 0; t < DK; ++t) {
+                const h8 kf = *reinterpret_cast<const h8*>(krow + t * 16);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t], s[kt], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (lane-local per query column) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = j0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float x = s[kt][r] * p.scale_log2e;
+                if (key >= p.nk) x = -INFINITY;
+                s[kt][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_i, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+                s[kt][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+        // B operand k-slot jj of (kt, s2) on lane hi carries key kt*32 + 16*s2 + 8*(jj>>2) + 4*hi + (jj&3)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                h8 pf;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)s[kt][8 * s2 + jj];
+                const int c0 = kt * 32 + 16 * s2 + 4 * hi;
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const half_t* vrow = sV + (t * 32 + l31) * VSTR + c0;
+                    const h4 va = *reinterpret_cast<const h4*>(vrow);
+                    const h4 vb = *reinterpret_cast<const h4*>(vrow + 8);
+                    h8 vf;
+                    vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
+                    vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- normalise and store: lane (q, hi) holds O[q, t*32 + 8*g + 4*hi + 0..3] ----
+    if (qok) {
+        const float inv = 1.0f / l_i;
+        half_t* orow = p.O + b * p.o_bs + (long)q * p.ldo + h * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = t * 32 + 8 * g + 4 * hi;
+                if (c < D) {
+                    h4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g + e] * inv);
+                    *reinterpret_cast<h4*>(orow + c) = pk;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch_attn(const AttnParams& p, long nb, hipStream_t stream) {
+    dim3 grid((unsigned)((p.nq + 127) / 128), (unsigned)p.heads, (unsigned)nb);
+    hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), 0, stream, p);
+    return vsx_check_launch("vsx_attention_f16");
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 — temporal self-attention across frames at each spatial site.  One wave per
+// (batch, site, head): Q/K/V rows of the site ([f, d], d contiguous in HBM) are staged in LDS,
+// scores and softmax in fp32.  FLOPs are negligible (0.1 % of the UNet); the kernel is bound by
+// the strided HBM reads, which adjacent heads of a site turn into full 128-byte lines in L2.
+// ---------------------------------------------------------------------------------------------
+struct TempParams {
+    const half_t* Q;
+    const half_t* K;
+    const half_t* V;
+    half_t* O;
+    int fq, fk, hw, heads, d;
+    long ldq, ldkv, ldo;
+    float scale;
+};
+
+__global__ __launch_bounds__(64) void temporal_attn_kernel(const TempParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int d = p.d, fq = p.fq, fk = p.fk;
+    half_t* sQ = reinterpret_cast<half_t*>(smem_raw);   // [fq][d]
+    half_t* sK = sQ + fq * d;                            // [fk][d]
+    half_t* sV = sK + fk * d;                            // [fk][d]
+    float* sS = reinterpret_cast<float*>(sV + fk * d);   // [fq][fk]
+
+    const int lane = threadIdx.x;
+    const long site = blockIdx.x;
+    const int h = blockIdx.y;
+    const long b = blockIdx.z;
+    const int dv = d >> 3;
+
+    for (int i = lane; i < fq * dv; i += 64) {
+        const int f = i / dv, c = (i - f * dv) * 8;
+        st16(sQ + f * d + c, ld16(p.Q + ((b * fq + f) * p.hw + site) * p.ldq + h * d + c));
+    }
+    for (int i = lane; i < fk * dv; i += 64) {
+        const int f = i / dv, c = (i - f * dv) * 8;
+        const long row = (b * fk + f) * p.hw + site;
+        st16(sK + f * d + c, ld16(p.K + row * p.ldkv + h * d + c));
+        st16(sV + f * d + c, ld16(p.V + row * p.ldkv + h * d + c));
+    }
+    __syncthreads();
+    for (int i = lane; i < fq * fk; i += 64) {
+        const int f = i / fk, g = i - f * fk;
+        float acc = 0.f;
+        for (int c = 0; c < d; c += 8) {
+            const h8 a = *reinterpret_cast<const h8*>(sQ + f * d + c);
+            const h8 k = *reinterpret_cast<const h8*>(sK + g * d + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)k[e];
+        }
+        sS[i] = acc * p.scale;
+    }
+    __syncthreads();
+    for (int f = lane; f < fq; f += 64) {
+        float mx = -INFINITY;
+        for (int g = 0; g < fk; ++g) mx = fmaxf(mx, sS[f * fk + g]);
+        float sum = 0.f;
+        for (int g = 0; g < fk; ++g) {
+            const float e = __expf(sS[f * fk + g] - mx);
+            sS[f * fk + g] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        for (int g = 0; g < fk; ++g) sS[f * fk + g] *= inv;
+    }
+    __syncthreads();
+    for (int i = lane; i < fq * dv; i += 64) {
+        const int f = i / dv, c = (i - f * dv) * 8;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int g = 0; g < fk; ++g) {
+            const float pr = sS[f * fk + g];
+            const h8 v = *reinterpret_cast<const h8*>(sV + g * d + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pr * (float)v[e];
+        }
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+        st16(p.O + ((b * fq + f) * p.hw + site) * p.ldo + h * d + c, as_u4(o));
+    }
+}
+
+}  // namespace
+
+extern "C" int vsx_attention_f16(const void* Q, const void* K, const void* VT, void* O, int64_t nb, int64_t heads,
+                                 int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk, int64_t ldvt,
+                                 int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t vt_bs, int64_t o_bs,
+                                 int64_t kv_div, float scale, vsx_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSX_REQUIRE(Q && K && VT && O, VSX_E_BADSHAPE, "attention: null tensor");
+    if (nb == 0 || nq == 0) return VSX_OK;
+    VSX_REQUIRE(nb > 0 && heads > 0 && nq > 0 && nk > 0 && kv_div > 0, VSX_E_BADSHAPE, "attention: bad sizes");
+    VSX_REQUIRE(nb <= 65535 && heads <= 65535, VSX_E_BADSHAPE, "attention: nb/heads exceed grid limits");
+    VSX_REQUIRE(vsx_aligned16(Q) && vsx_aligned16(K) && vsx_aligned16(VT) && vsx_aligned16(O), VSX_E_BADSHAPE,
+                "attention: tensors must be 16-byte aligned");
+    VSX_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, VSX_E_BADSHAPE,
+                "attention: row strides must be multiples of 8 (ldo: 4)");
+    VSX_REQUIRE(q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0 && o_bs % 4 == 0, VSX_E_BADSHAPE,
+                "attention: batch strides must be multiples of 8");
+    VSX_REQUIRE(ldvt >= ((nk + 7) / 8) * 8, VSX_E_BADSHAPE, "attention: ldvt (%ld) < round_up(nk=%ld, 8)", (long)ldvt,
+                (long)nk);
+    AttnParams p;
+    p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.VT = (const half_t*)VT; p.O = (half_t*)O;
+    p.nq = (int)nq; p.nk = (int)nk; p.heads = (int)heads;
+    p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+    p.q_bs = q_bs; p.k_bs = k_bs; p.vt_bs = vt_bs; p.o_bs = o_bs;
+    p.kv_div = (int)kv_div;
+    p.scale_log2e = scale * 1.44269504088896340736f;
+    switch (d) {
+        case 8: return launch_attn<8>(p, nb, stream);
+        case 16: return launch_attn<16>(p, nb, stream);
+        case 32: return launch_attn<32>(p, nb, stream);
+        case 40: return launch_attn<40>(p, nb, stream);
+        case 64: return launch_attn<64>(p, nb, stream);
+        case 80: return launch_attn<80>(p, nb, stream);
+        case 128: return launch_attn<128>(p, nb, stream);
+        case 160: return launch_attn<160>(p, nb, stream);
+        default: return vsx_fail(VSX_E_UNSUPPORTED, "attention: head dim %ld not in {8,16,32,40,64,80,128,160}", (long)d);
+    }
+}
+
+extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const void* V, void* O, int64_t B, int64_t fq,
+                                          int64_t fk, int64_t hw, int64_t heads, int64_t d, int64_t ldq, int64_t ldkv,
+                                          int64_t ldo, float scale, vsx_stream_t stream) {
+    VSX_REQUIRE(Q && K && V && O, VSX_E_BADSHAPE, "temporal_attention: null tensor");
+    if (B == 0 || hw == 0) return VSX_OK;
+    VSX_REQUIRE(B > 0 && fq > 0 && fk > 0 && hw > 0 && heads > 0 && d > 0, VSX_E_BADSHAPE, "temporal_attention: bad sizes");
+    VSX_REQUIRE(d % 8 == 0 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0, VSX_E_BADSHAPE,
+                "temporal_attention: d and row strides must be multiples of 8");
+    VSX_REQUIRE(vsx_aligned16(Q) && vsx_aligned16(K) && vsx_aligned16(V) && vsx_aligned16(O), VSX_E_BADSHAPE,
+                "temporal_attention: tensors must be 16-byte aligned");
+    VSX_REQUIRE(B <= 65535 && heads <= 65535, VSX_E_BADSHAPE, "temporal_attention: grid limits");
+    const size_t smem = (size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float);
+    VSX_REQUIRE(smem <= 160 * 1024, VSX_E_UNSUPPORTED, "temporal_attention: %zu bytes of LDS needed (> 160 KiB)", smem);
+    static size_t smem_attr = 64 * 1024;
+    if (smem > smem_attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "temporal_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        smem_attr = 160 * 1024;
+    }
+    TempParams p;
+    p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
+    p.fq = (int)fq; p.fk = (int)fk; p.hw = (int)hw; p.heads = (int)heads; p.d = (int)d;
+    p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.scale = scale;
+    dim3 grid((unsigned)hw, (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(temporal_attn_kernel, grid, dim3(64), smem, (hipStream_t)stream, p);
+    return vsx_check_launch("vsx_temporal_attention_f16");
+}

@@ -1,0 +1,269 @@
+// K3/K4 — GroupNorm (two-kernel, channels-last, optional two-source concat) and LayerNorm
+// (+ fused temporal positional encoding) for gfx950.  HBM-bound: 16-byte vector loads/stores,
+// fp32 statistics, deterministic reduction order (no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_STAT_THREADS = 512;
+constexpr int GN_STAT_ROWS = 256;   // rows per statistics chunk
+constexpr int GN_APPLY_ROWS = 32;   // rows per apply block
+constexpr int GN_MAX_GROUPS = 64;
+
+__device__ __forceinline__ uint4 gn_load(const half_t* x1, const half_t* x2, long row, int c, int C1, int C2) {
+    return (c < C1) ? ld16(x1 + row * C1 + c) : ld16(x2 + row * C2 + (c - C1));
+}
+
+// grid (nchunks, nimg), block 512.
+__global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t* __restrict__ x1,
+                                                                   const half_t* __restrict__ x2, long rows, int C1,
+                                                                   int C2, int groups, float* __restrict__ partial) {
+    __shared__ float red_s[4096];
+    __shared__ float red_q[4096];
+    const int C = C1 + C2;
+    const int vpr = C >> 3;                   // vectors per row (<= 512)
+    const int rp = GN_STAT_THREADS / vpr;      // rows per pass (>= 1)
+    const int tid = threadIdx.x;
+    const int rl = tid / vpr;
+    const int cv = tid - rl * vpr;
+    const int chunk = blockIdx.x;
+    const long img = blockIdx.y;
+    const long r0 = (long)chunk * GN_STAT_ROWS;
+    const long r1 = min(r0 + (long)GN_STAT_ROWS, rows);
+
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (rl < rp) {
+        for (long r = r0 + rl; r < r1; r += rp) {
+            const h8 v = as_h8(gn_load(x1, x2, img * rows + r, cv * 8, C1, C2));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s[e] += f;
+                q[e] += f * f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red_s[rl * C + cv * 8 + e] = s[e];
+            red_q[rl * C + cv * 8 + e] = q[e];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += GN_STAT_THREADS) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < rp; ++r) { a += red_s[r * C + c]; b += red_q[r * C + c]; }
+        red_s[c] = a;
+        red_q[c] = b;
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const int cpg = C / groups;
+        float a = 0.f, b = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += red_s[c]; b += red_q[c]; }
+        float* out = partial + ((img * gridDim.x + chunk) * groups + tid) * 2;
+        out[0] = a;
+        out[1] = b;
+    }
+}
+
+// grid (ceil(rows/GN_APPLY_ROWS), nimg), block 256.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2,
+                                                       long rows, int C1, int C2, int groups,
+                                                       const float* __restrict__ partial, int nchunks, float inv_count,
+                                                       const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                       float eps, int silu, half_t* __restrict__ y) {
+    __shared__ float s_mean[GN_MAX_GROUPS];
+    __shared__ float s_rstd[GN_MAX_GROUPS];
+    const int C = C1 + C2;
+    const int cpg = C / groups;
+    const int tid = threadIdx.x;
+    const long img = blockIdx.y;
+    if (tid < groups) {
+        float a = 0.f, b = 0.f;
+        const float* pp = partial + (img * nchunks * groups + tid) * 2;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            a += pp[(long)ch * groups * 2];
+            b += pp[(long)ch * groups * 2 + 1];
+        }
+        const float mean = a * inv_count;
+        const float var = fmaxf(b * inv_count - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const int vpr = C >> 3;
+    const long r0 = (long)blockIdx.x * GN_APPLY_ROWS;
+    const long nrow = min((long)GN_APPLY_ROWS, rows - r0);
+    const long nvec = nrow * vpr;
+    for (long i = tid; i < nvec; i += 256) {
+        const long r = i / vpr;
+        const int c = (int)(i - r * vpr) * 8;
+        const long row = img * rows + r0 + r;
+        const h8 v = as_h8(gn_load(x1, x2, row, c, C1, C2));
+        const h8 gm = as_h8(ld16(gamma + c));
+        const h8 bt = as_h8(ld16(beta + c));
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / cpg;
+            float f = ((float)v[e] - s_mean[g]) * s_rstd[g] * (float)gm[e] + (float)bt[e];
+            if (silu) f = silu_f(f);
+            o[e] = (half_t)f;
+        }
+        st16(y + row * C + c, as_u4(o));
+    }
+}
+
+// one wave per row, 4 rows per block; C <= 2048.
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long M, int C,
+                                                        const half_t* __restrict__ gamma,
+                                                        const half_t* __restrict__ beta, float eps,
+                                                        const half_t* __restrict__ pe, long rows_per_frame, int frames,
+                                                        int frame_offset, half_t* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int vpr = C >> 3;
+    float f[4][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int v = lane + 64 * k;
+        if (v < vpr) {
+            const h8 h = as_h8(ld16(x + m * C + v * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[k][e] = (float)h[e]; sum += f[k][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[k][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int v = lane + 64 * k;
+        if (v < vpr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[k][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const half_t* perow = nullptr;
+    if (pe) {
+        const long fr = (m / rows_per_frame) % frames + frame_offset;
+        perow = pe + fr * C;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int v = lane + 64 * k;
+        if (v < vpr) {
+            const h8 gm = as_h8(ld16(gamma + v * 8));
+            const h8 bt = as_h8(ld16(beta + v * 8));
+            h8 o;
+            if (perow) {
+                const h8 pv = as_h8(ld16(perow + v * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e] = (half_t)((f[k][e] - mean) * rstd * (float)gm[e] + (float)bt[e] + (float)pv[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)((f[k][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+            }
+            st16(y + m * C + v * 8, as_u4(o));
+        }
+    }
+}
+
+// in-place row softmax, one wave per row (fp16 storage, fp32 math).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ S, long nrows, int ncols, long ld) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    half_t* row = S + r * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < ncols; c += 64) mx = fmaxf(mx, (float)row[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < ncols; c += 64) sum += __expf((float)row[c] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < ncols; c += 64) row[c] = (half_t)(__expf((float)row[c] - mx) * inv);
+}
+
+}  // namespace
+
+extern "C" int64_t vsx_groupnorm_chunks(int64_t rows) { return (rows + GN_STAT_ROWS - 1) / GN_STAT_ROWS; }
+
+static int gn_check(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1, int64_t C2,
+                    int64_t groups) {
+    VSX_REQUIRE(x1 && nimg > 0 && rows > 0, VSX_E_BADSHAPE, "groupnorm: empty input");
+    VSX_REQUIRE(C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0, VSX_E_BADSHAPE,
+                "groupnorm: channels must be multiples of 8 (C1=%ld C2=%ld)", (long)C1, (long)C2);
+    VSX_REQUIRE((C2 == 0) == (x2 == nullptr), VSX_E_BADSHAPE, "groupnorm: x2/C2 mismatch");
+    const int64_t C = C1 + C2;
+    VSX_REQUIRE(C <= 4096, VSX_E_UNSUPPORTED, "groupnorm: C=%ld > 4096", (long)C);
+    VSX_REQUIRE(groups > 0 && groups <= GN_MAX_GROUPS && C % groups == 0, VSX_E_BADSHAPE,
+                "groupnorm: groups=%ld does not divide C=%ld (max %d groups)", (long)groups, (long)C, GN_MAX_GROUPS);
+    VSX_REQUIRE(vsx_aligned16(x1) && vsx_aligned16(x2), VSX_E_BADSHAPE, "groupnorm: inputs must be 16-byte aligned");
+    VSX_REQUIRE(nimg <= 65535, VSX_E_BADSHAPE, "groupnorm: nimg=%ld > 65535", (long)nimg);
+    return VSX_OK;
+}
+
+extern "C" int vsx_groupnorm_stats(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
+                                   int64_t C2, int64_t groups, float* partial, vsx_stream_t stream) {
+    int rc = gn_check(x1, x2, nimg, rows, C1, C2, groups);
+    if (rc) return rc;
+    VSX_REQUIRE(partial != nullptr, VSX_E_WORKSPACE, "groupnorm_stats: null partial buffer");
+    dim3 grid((unsigned)vsx_groupnorm_chunks(rows), (unsigned)nimg);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_STAT_THREADS), 0, (hipStream_t)stream, (const half_t*)x1,
+                       (const half_t*)x2, (long)rows, (int)C1, (int)C2, (int)groups, partial);
+    return vsx_check_launch("vsx_groupnorm_stats");
+}
+
+extern "C" int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
+                                   int64_t C2, int64_t groups, const float* partial, int64_t nchunks,
+                                   int64_t count_rows, const void* gamma, const void* beta, float eps, int64_t silu,
+                                   void* y, vsx_stream_t stream) {
+    int rc = gn_check(x1, x2, nimg, rows, C1, C2, groups);
+    if (rc) return rc;
+    VSX_REQUIRE(partial && gamma && beta && y, VSX_E_BADSHAPE, "groupnorm_apply: null argument");
+    VSX_REQUIRE(nchunks > 0 && count_rows > 0, VSX_E_BADSHAPE, "groupnorm_apply: nchunks/count_rows");
+    VSX_REQUIRE(vsx_aligned16(gamma) && vsx_aligned16(beta) && vsx_aligned16(y), VSX_E_BADSHAPE,
+                "groupnorm_apply: gamma/beta/y must be 16-byte aligned");
+    const int64_t C = C1 + C2;
+    const float inv_count = 1.0f / ((float)count_rows * (float)(C / groups));
+    dim3 grid((unsigned)((rows + GN_APPLY_ROWS - 1) / GN_APPLY_ROWS), (unsigned)nimg);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
+                       (long)rows, (int)C1, (int)C2, (int)groups, partial, (int)nchunks, inv_count,
+                       (const half_t*)gamma, (const half_t*)beta, eps, (int)silu, (half_t*)y);
+    return vsx_check_launch("vsx_groupnorm_apply");
+}
+
+extern "C" int vsx_layernorm(const void* x, int64_t M, int64_t C, const void* gamma, const void* beta, float eps,
+                             const void* pe, int64_t rows_per_frame, int64_t frames, int64_t frame_offset, void* y,
+                             vsx_stream_t stream) {
+    VSX_REQUIRE(x && gamma && beta && y, VSX_E_BADSHAPE, "layernorm: null argument");
+    if (M == 0) return VSX_OK;
+    VSX_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, VSX_E_BADSHAPE, "layernorm: C=%ld must be a multiple of 8, <= 2048",
+                (long)C);
+    VSX_REQUIRE(vsx_aligned16(x) && vsx_aligned16(gamma) && vsx_aligned16(beta) && vsx_aligned16(y) && vsx_aligned16(pe),
+                VSX_E_BADSHAPE, "layernorm: pointers must be 16-byte aligned");
+    if (pe) VSX_REQUIRE(rows_per_frame > 0 && frames > 0 && frame_offset >= 0, VSX_E_BADSHAPE, "layernorm: pe geometry");
+    const long blocks = (M + 3) / 4;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (long)M, (int)C, (const half_t*)gamma, (const half_t*)beta, eps, (const half_t*)pe,
+                       (long)(rows_per_frame > 0 ? rows_per_frame : 1), (int)(frames > 0 ? frames : 1),
+                       (int)frame_offset, (half_t*)y);
+    return vsx_check_launch("vsx_layernorm");
+}
+
+extern "C" int vsx_softmax_rows(void* S, int64_t nrows, int64_t ncols, int64_t ld, vsx_stream_t stream) {
+    VSX_REQUIRE(S != nullptr && ncols > 0 && ld >= ncols, VSX_E_BADSHAPE, "softmax_rows: bad arguments");
+    if (nrows == 0) return VSX_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (half_t*)S, (long)nrows, (int)ncols, (long)ld);
+    return vsx_check_launch("vsx_softmax_rows");
+}

@@ -1,0 +1,360 @@
+"""Tensor-level wrappers over the libvsx C ABI.
+
+PyTorch is used for device memory and the HIP stream only: every function here takes fp16 CUDA
+(ROCm) tensors, hands raw pointers + the current stream to a hand-written gfx950 kernel and
+returns the output tensor.  There is no fallback implementation.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+_F16 = torch.float16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, dtype=_F16):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.VsxError(f'{name}: expected a GPU tensor (the denoising path has no CPU implementation)')
+    if t.dtype != dtype:
+        raise _lib.VsxError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise _lib.VsxError(f'{name}: expected a contiguous tensor, got strides {t.stride()}')
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------------------------
+# GEMM family
+# --------------------------------------------------------------------------------------------
+def gemm(desc):
+    check(_lib.load().vsx_gemm_f16(ctypes.byref(desc), _stream()), 'vsx_gemm_f16')
+
+
+def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
+    """y = x @ weight.T (+bias) (+residual); geglu: weight is [2N,K], y = h * gelu(g).
+
+    x [..., K] -> [..., N].  Replaces nn.Linear / 1x1 conv / diffusers GEGLU.
+    """
+    _chk(x, 'x'); _chk(weight, 'weight'); _chk(bias, 'bias'); _chk(residual, 'residual')
+    K = x.shape[-1]
+    M = x.numel() // K
+    if weight.dim() == 4:  # 1x1 conv weight [N,K,1,1]
+        weight = weight.reshape(weight.shape[0], weight.shape[1])
+    n_rows = weight.shape[0]
+    if weight.shape[1] != K:
+        raise _lib.VsxError(f'linear: weight {tuple(weight.shape)} does not match input features {K}')
+    N = n_rows // 2 if geglu else n_rows
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, dtype=_F16, device=x.device)
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.batch0 = d.batch1 = 1
+    d.A = x.data_ptr(); d.lda = K
+    d.B = weight.data_ptr(); d.ldb = K
+    d.C = out.data_ptr(); d.ldc = N
+    d.bias = bias.data_ptr() if bias is not None else None
+    if residual is not None:
+        if residual.numel() != M * N:
+            raise _lib.VsxError('linear: residual shape mismatch')
+        d.residual = residual.data_ptr(); d.ldr = N
+    d.geglu = 1 if geglu else 0
+    d.alpha = 1.0
+    gemm(d)
+    return out
+
+
+def linear_vt(x, weight, bias, rows_per_img, ldvt=None):
+    """V^T projection: x [nimg*rows, K] -> VT [nimg, N, ldvt] with VT[i, n, r] = (x @ W.T)[i*rows + r, n].
+
+    Feeds vsx_attention_f16 / attention_pv (V is consumed key-contiguous).  Columns >= rows of VT are left
+    untouched (the consumers mask them).
+    """
+    _chk(x, 'x'); _chk(weight, 'weight'); _chk(bias, 'bias')
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = weight.shape[0]
+    nimg = M // rows_per_img
+    if ldvt is None:
+        ldvt = round_up(rows_per_img, 8)
+    vt = torch.empty(nimg, N, ldvt, dtype=_F16, device=x.device)
+    if ldvt != rows_per_img:
+        vt.zero_()
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.batch0 = d.batch1 = 1
+    d.A = x.data_ptr(); d.lda = K
+    d.B = weight.data_ptr(); d.ldb = K
+    d.C = vt.data_ptr(); d.ldc = ldvt
+    d.c_mode = 1; d.c_rows_per_img = rows_per_img; d.c_img_stride = N * ldvt
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.alpha = 1.0
+    gemm(d)
+    return vt
+
+
+def conv2d(x, weight, bias=None, *, x2=None, stride=1, upsample=False, rowvec=None, rows_per_vec=0,
+           residual=None):
+    """Channels-last conv as implicit GEMM.
+
+    x [nimg, H, W, C1] (+ x2 [nimg, H, W, C2] concatenated on C); weight [Cout, ks, ks, C1+C2] contiguous
+    (== a channels_last-format nn.Conv2d weight); returns [nimg, Ho, Wo, Cout].  `upsample`: x/x2 are at half
+    resolution and are read as their nearest-2x upsampling.  rowvec [nvec, Cout] is added to rows
+    [i*rows_per_vec, (i+1)*rows_per_vec) (time embedding); residual [nimg, Ho, Wo, Cout] is added last.
+    """
+    _chk(x, 'x'); _chk(x2, 'x2'); _chk(weight, 'weight'); _chk(bias, 'bias'); _chk(rowvec, 'rowvec')
+    _chk(residual, 'residual')
+    nimg, Hs, Ws, C1 = x.shape
+    C2 = x2.shape[-1] if x2 is not None else 0
+    Cout, ks = weight.shape[0], weight.shape[1]
+    if weight.shape[2] != ks or weight.shape[3] != C1 + C2:
+        raise _lib.VsxError(f'conv2d: weight {tuple(weight.shape)} does not match input channels {C1}+{C2}')
+    H, W = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
+    pad = ks // 2
+    Ho = (H + 2 * pad - ks) // stride + 1
+    Wo = (W + 2 * pad - ks) // stride + 1
+    out = torch.empty(nimg, Ho, Wo, Cout, dtype=_F16, device=x.device)
+    d = GemmDesc()
+    d.M, d.N, d.K = nimg * Ho * Wo, Cout, ks * ks * (C1 + C2)
+    d.batch0 = d.batch1 = 1
+    d.A = x.data_ptr(); d.A2 = x2.data_ptr() if x2 is not None else None
+    d.a_mode = 1; d.H, d.W, d.C1, d.C2 = H, W, C1, C2
+    d.ks, d.stride, d.upsample = ks, stride, 1 if upsample else 0
+    d.B = weight.data_ptr(); d.ldb = d.K
+    d.C = out.data_ptr(); d.ldc = Cout
+    d.bias = bias.data_ptr() if bias is not None else None
+    if rowvec is not None:
+        d.rowvec = rowvec.data_ptr(); d.rows_per_vec = rows_per_vec
+    if residual is not None:
+        if residual.numel() != out.numel():
+            raise _lib.VsxError('conv2d: residual shape mismatch')
+        d.residual = residual.data_ptr(); d.ldr = Cout
+    d.alpha = 1.0
+    gemm(d)
+    return out
+
+
+def attention_scores(q, k, heads, scale, kv_div=1):
+    """probs = softmax(scale * q k^T) materialised (the Prompt-to-Prompt hook path).
+
+    q [nb, nq, C], k [nkvb, nk, C] -> probs [nb, heads, nq, nk] (a view of a buffer whose rows are padded to a
+    multiple of 8 so that probs @ V can stream it with 16-byte loads)."""
+    _chk(q, 'q'); _chk(k, 'k')
+    nb, nq, C = q.shape
+    nk = k.shape[1]
+    dh = C // heads
+    ld = round_up(nk, 8)
+    buf = torch.empty(nb, heads, nq, ld, dtype=_F16, device=q.device)
+    if ld != nk:
+        buf.zero_()
+    if kv_div == 1:
+        d = GemmDesc()
+        d.M, d.N, d.K = nq, nk, dh
+        d.batch0, d.batch1 = nb, heads
+        d.A = q.data_ptr(); d.lda = C; d.a_bs0 = nq * C; d.a_bs1 = dh
+        d.B = k.data_ptr(); d.ldb = C; d.b_bs0 = nk * C; d.b_bs1 = dh
+        d.C = buf.data_ptr(); d.ldc = ld; d.c_bs0 = heads * nq * ld; d.c_bs1 = nq * ld
+        d.alpha = float(scale)
+        gemm(d)
+    else:
+        for kb in range(k.shape[0]):  # text K shared by kv_div consecutive images
+            d = GemmDesc()
+            d.M, d.N, d.K = nq, nk, dh
+            d.batch0, d.batch1 = kv_div, heads
+            sl = q[kb * kv_div:(kb + 1) * kv_div]
+            d.A = sl.data_ptr(); d.lda = C; d.a_bs0 = nq * C; d.a_bs1 = dh
+            d.B = k[kb].data_ptr(); d.ldb = C; d.b_bs0 = 0; d.b_bs1 = dh
+            d.C = buf[kb * kv_div:(kb + 1) * kv_div].data_ptr(); d.ldc = ld
+            d.c_bs0 = heads * nq * ld; d.c_bs1 = nq * ld
+            d.alpha = float(scale)
+            gemm(d)
+    check(_lib.load().vsx_softmax_rows(_p(buf), nb * heads * nq, nk, ld, _stream()), 'vsx_softmax_rows')
+    return buf[..., :nk]
+
+
+def attention_pv(probs, vt, kv_div=1):
+    """out[b, q, h*d + c] = sum_t probs[b, h, q, t] * vt[b // kv_div, h*d + c, t]; probs from attention_scores
+    (possibly edited in place by a controller; must still be a view of a buffer with padded rows)."""
+    nb, heads, nq, nk = probs.shape
+    ld = probs.stride(2)
+    if probs.stride(3) != 1 or probs.stride(1) != nq * ld or probs.stride(0) != heads * nq * ld or ld % 8:
+        ld = round_up(nk, 8)
+        buf = torch.zeros(nb, heads, nq, ld, dtype=_F16, device=probs.device)
+        buf[..., :nk] = probs
+        probs = buf[..., :nk]
+    if probs.dtype != _F16 or not probs.is_cuda:
+        raise _lib.VsxError('attention_pv: probs must be an fp16 GPU tensor')
+    _chk(vt, 'vt')
+    C, ldvt = vt.shape[1], vt.shape[2]
+    dh = C // heads
+    out = torch.empty(nb, nq, C, dtype=_F16, device=probs.device)
+    # K (reduction) = nk rounded up to 8: padded columns of probs are zero, padded VT columns masked by them
+    kred = round_up(nk, 8)
+    if ldvt < kred:
+        raise _lib.VsxError('attention_pv: vt rows are shorter than round_up(nk, 8)')
+    groups = [(0, nb, 0)] if kv_div == 1 else [(kb * kv_div, kv_div, kb) for kb in range(vt.shape[0])]
+    for (b0, cnt, kb) in groups:
+        d = GemmDesc()
+        d.M, d.N, d.K = nq, dh, kred
+        d.batch0, d.batch1 = cnt, heads
+        d.A = probs[b0:].data_ptr(); d.lda = ld; d.a_bs0 = heads * nq * ld; d.a_bs1 = nq * ld
+        d.B = vt[kb if kv_div != 1 else b0:].data_ptr(); d.ldb = ldvt
+        d.b_bs0 = 0 if kv_div != 1 else C * ldvt; d.b_bs1 = dh * ldvt
+        d.C = out[b0:].data_ptr(); d.ldc = C; d.c_bs0 = nq * C; d.c_bs1 = dh
+        d.alpha = 1.0
+        gemm(d)
+    return out
+
+
+def attention(q, k, vt, heads, scale, kv_div=1, nk=None):
+    """Fused softmax(q k^T * scale) v.  q [nb,nq,C]; k [nkvb,nk,C]; vt [nkvb,C,ldvt] -> [nb,nq,C]."""
+    _chk(q, 'q'); _chk(k, 'k'); _chk(vt, 'vt')
+    nb, nq, C = q.shape
+    nk = k.shape[1] if nk is None else nk
+    dh = C // heads
+    out = torch.empty_like(q)
+    check(_lib.load().vsx_attention_f16(_p(q), _p(k), _p(vt), _p(out), nb, heads, nq, nk, dh, C, C, vt.shape[2], C,
+                                        nq * C, k.shape[1] * C, C * vt.shape[2], nq * C, kv_div, float(scale),
+                                        _stream()), 'vsx_attention_f16')
+    return out
+
+
+def temporal_attention(q, k, v, B, fq, fk, hw, heads, scale):
+    """q [B*fq*hw, C], k/v [B*fk*hw, C] in (b, f, site) row order -> [B*fq*hw, C]."""
+    _chk(q, 'q'); _chk(k, 'k'); _chk(v, 'v')
+    C = q.shape[-1]
+    out = torch.empty_like(q)
+    check(_lib.load().vsx_temporal_attention_f16(_p(q), _p(k), _p(v), _p(out), B, fq, fk, hw, heads, C // heads, C, C,
+                                                 C, float(scale), _stream()), 'vsx_temporal_attention_f16')
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# normalisation
+# --------------------------------------------------------------------------------------------
+def group_norm(x, gamma, beta, groups, eps, nimg, silu=False, x2=None, partial_hook=None, count_rows=None):
+    """GroupNorm over channels-last x (viewed as [nimg, rows, C1]) (+x2 concatenated on C) -> [.., C1+C2].
+
+    nimg = B reproduces the reference's 5-D GroupNorm (statistics over all frames), nimg = B*F the per-frame one.
+    partial_hook(partial) may all-reduce the fp32 partial sums in frame-sharded mode (count_rows = global rows).
+    """
+    _chk(x, 'x'); _chk(x2, 'x2'); _chk(gamma, 'gamma'); _chk(beta, 'beta')
+    C1 = x.shape[-1]
+    C2 = x2.shape[-1] if x2 is not None else 0
+    rows = x.numel() // C1 // nimg
+    lib = _lib.load()
+    nchunks = lib.vsx_groupnorm_chunks(rows)
+    partial = torch.empty(nimg, nchunks, groups, 2, dtype=torch.float32, device=x.device)
+    s = _stream()
+    check(lib.vsx_groupnorm_stats(_p(x), _p(x2), nimg, rows, C1, C2, groups, _p(partial), s), 'vsx_groupnorm_stats')
+    if partial_hook is not None:
+        partial = partial_hook(partial)
+        nchunks = partial.shape[1]
+    y = torch.empty(*x.shape[:-1], C1 + C2, dtype=_F16, device=x.device)
+    check(lib.vsx_groupnorm_apply(_p(x), _p(x2), nimg, rows, C1, C2, groups, _p(partial), nchunks,
+                                  rows if count_rows is None else count_rows, _p(gamma), _p(beta), float(eps),
+                                  1 if silu else 0, _p(y), s), 'vsx_groupnorm_apply')
+    return y
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0, frame_offset=0):
+    _chk(x, 'x'); _chk(gamma, 'gamma'); _chk(beta, 'beta'); _chk(pe, 'pe')
+    C = x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.load().vsx_layernorm(_p(x), x.numel() // C, C, _p(gamma), _p(beta), float(eps), _p(pe), rows_per_frame,
+                                    frames, frame_offset, _p(y), _stream()), 'vsx_layernorm')
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# element-wise glue
+# --------------------------------------------------------------------------------------------
+def silu(x):
+    _chk(x, 'x')
+    y = torch.empty_like(x)
+    check(_lib.load().vsx_silu(_p(x), _p(y), x.numel(), _stream()), 'vsx_silu')
+    return y
+
+
+def axpy(a, b, s=1.0):
+    _chk(a, 'a'); _chk(b, 'b')
+    if a.shape != b.shape:
+        raise _lib.VsxError(f'axpy: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}')
+    y = torch.empty_like(a)
+    check(_lib.load().vsx_axpy(_p(a), _p(b), float(s), _p(y), a.numel(), _stream()), 'vsx_axpy')
+    return y
+
+
+def pack_latents(x, cpad=8):
+    """[B,C,F,H,W] -> channels-last [B*F,H,W,cpad] (zero-padded channels)."""
+    _chk(x, 'x')
+    B, C, F, H, W = x.shape
+    y = torch.empty(B * F, H, W, cpad, dtype=_F16, device=x.device)
+    check(_lib.load().vsx_pack_latents(_p(x), _p(y), B, C, F, H * W, cpad, _stream()), 'vsx_pack_latents')
+    return y
+
+
+def unpack_latents(x, B, cout):
+    """channels-last [B*F,H,W,Cs] -> [B,cout,F,H,W]."""
+    _chk(x, 'x')
+    BF, H, W, Cs = x.shape
+    F = BF // B
+    y = torch.empty(B, cout, F, H, W, dtype=_F16, device=x.device)
+    check(_lib.load().vsx_unpack_latents(_p(x), _p(y), B, cout, F, H * W, Cs, _stream()), 'vsx_unpack_latents')
+    return y
+
+
+def cfg_ddim_step(x, eps_u, eps_c, guidance, alpha_t, alpha_next):
+    _chk(x, 'x'); _chk(eps_u, 'eps_u'); _chk(eps_c, 'eps_c')
+    out = torch.empty_like(x)
+    check(_lib.load().vsx_cfg_ddim_step(_p(x), _p(eps_u), _p(eps_c), float(guidance), float(alpha_t),
+                                        float(alpha_next), _p(out), x.numel(), _stream()), 'vsx_cfg_ddim_step')
+    return out
+
+
+def masked_blend(x, src, mask):
+    """x, src [C, ...spatial]; mask [...spatial] -> src + mask*(x-src)."""
+    _chk(x, 'x'); _chk(src, 'src'); _chk(mask, 'mask')
+    C = x.shape[0]
+    n_sp = x.numel() // C
+    if mask.numel() != n_sp or src.shape != x.shape:
+        raise _lib.VsxError('masked_blend: shape mismatch')
+    out = torch.empty_like(x)
+    check(_lib.load().vsx_masked_blend(_p(x), _p(src), _p(mask), _p(out), C, n_sp, _stream()), 'vsx_masked_blend')
+    return out
+
+
+def adapter_scatter(tracks, selected, feat, h, w, rate, out_scale=1.0):
+    """tracks [F,P,2] fp32, selected [P] int32, feat [P,C] fp16 -> [F,h,w,C] fp16."""
+    _chk(tracks, 'tracks', torch.float32); _chk(selected, 'selected', torch.int32); _chk(feat, 'feat')
+    F, P = tracks.shape[:2]
+    C = feat.shape[1]
+    out = torch.zeros(F, h, w, C, dtype=_F16, device=feat.device)
+    check(_lib.load().vsx_adapter_scatter(_p(tracks), _p(selected), _p(feat), _p(out), F, P, C, h, w, float(rate),
+                                          float(out_scale), _stream()), 'vsx_adapter_scatter')
+    return out
+
+
+def prof_enable(on, max_samples=4096):
+    check(_lib.load().vsx_prof_enable(1 if on else 0, max_samples), 'vsx_prof_enable')
+
+
+def prof_collect():
+    n = ctypes.c_int64(0)
+    ms = ctypes.c_double(0)
+    fl = ctypes.c_double(0)
+    check(_lib.load().vsx_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'vsx_prof_collect')
+    return n.value, ms.value, fl.value
