@@ -1,0 +1,81 @@
+"""GPU parity of the HIP-backed AnimateDiffUNet3DModel against the golden vectors produced by the reference's own
+model code (tests/golden/unet_tiny.pt) and against the fp32 CPU oracle.
+
+Tolerance: the fp16 GPU result must be within 2x the rel-L2 error that the oracle itself shows
+when run with fp16 storage (measured in this test on the CPU), both taken against the fp32 result."""
+import copy
+
+import pytest
+import torch
+
+from util import cosine, load_golden, oracle_unet, product_unet_from, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def setup():
+    blob = load_golden('unet_tiny.pt')
+    ora = oracle_unet(blob['config'], blob['weight_seed'])
+    prod = product_unet_from(ora, blob['config'])
+    return blob, ora, prod
+
+
+def run_product(prod, case):
+    res = None
+    if case['residuals'] is not None:
+        res = [r.half().cuda() for r in case['residuals']]
+    with torch.no_grad():
+        out = prod(case['sample'].half().cuda(), torch.tensor(case['timestep']), case['text'].half().cuda(),
+                   down_block_additional_residuals=res, return_dict=False)[0]
+    torch.cuda.synchronize()
+    return out.float().cpu()
+
+
+@pytest.mark.parametrize('name', ['plain_T4_16x16', 'cfg_adapter_T3_16x24', 'first_inverse_step_t-19'])
+def test_unet_matches_reference_golden(setup, name):
+    blob, ora, prod = setup
+    case = blob['cases'][name]
+    half = copy.deepcopy(ora).half()
+    res = None if case['residuals'] is None else [r.half() for r in case['residuals']]
+    with torch.no_grad():
+        e16 = rel_l2(half(case['sample'].half(), torch.tensor(case['timestep']), case['text'].half(),
+                          down_block_additional_residuals=res).sample.float(), case['out'])
+    out = run_product(prod, case)
+    assert out.shape == case['out'].shape
+    err = rel_l2(out, case['out'])
+    print(f'{name}: gpu rel-L2 {err:.3e} (fp16-oracle {e16:.3e}) cos {cosine(out, case["out"]):.8f}')
+    assert torch.isfinite(out).all()
+    assert err <= 2 * e16, f'{name}: rel-L2 {err:.3e} > 2 x fp16-emulation error {e16:.3e}'
+
+
+def test_unet_output_object_and_determinism(setup):
+    blob, ora, prod = setup
+    case = blob['cases']['plain_T4_16x16']
+    x, txt = case['sample'].half().cuda(), case['text'].half().cuda()
+    with torch.no_grad():
+        a = prod(x, 481, txt)
+        b = prod(x, torch.tensor([481]), txt, return_dict=False)
+    assert hasattr(a, 'sample') and isinstance(b, tuple)
+    assert torch.equal(a.sample, b[0]), 'the forward must be bit-deterministic (no atomics anywhere)'
+    assert a.sample.shape == x.shape and a.sample.dtype == torch.float16
+
+
+def test_unet_pops_adapter_residual_list(setup):
+    blob, ora, prod = setup
+    case = blob['cases']['cfg_adapter_T3_16x24']
+    res = [r.half().cuda() for r in case['residuals']]
+    with torch.no_grad():
+        prod(case['sample'].half().cuda(), 21, case['text'].half().cuda(), down_block_additional_residuals=res)
+    assert res == []          # the UNet pops from the caller's list (unet.py:422,435)
+
+
+def test_zero_initialised_motion_module_is_identity(setup):
+    """With AnimateDiff's zero-init proj_out the temporal path must contribute exactly nothing."""
+    blob, ora, prod = setup
+    from videoswap_amd.unet import VanillaTemporalModule, Geometry
+    mm = VanillaTemporalModule(64, temporal_position_encoding=True, num_transformer_block=1).half().cuda()
+    x = torch.randn(8, 4, 4, 64, device='cuda', dtype=torch.float16)
+    with torch.no_grad():
+        y = mm(x, Geometry(2, 4))
+    assert torch.equal(x, y)
