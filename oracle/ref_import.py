@@ -58,6 +58,11 @@ def install_stubs():
     if 'torchvision' not in sys.modules:   # motion_module.py:8 imports it and never uses it
         tv = _package('torchvision')
         tv.utils = _module('torchvision.utils', save_image=lambda *a, **k: None)
+    if 'cv2' not in sys.modules:           # ptp_utils.py:5 (drawing helpers only)
+        _module('cv2')
+    if 'omegaconf' not in sys.modules:     # ptp_utils.py:7 (isinstance check against DictConfig only)
+        oc = _package('omegaconf')
+        oc.dictconfig = _module('omegaconf.dictconfig', DictConfig=type('DictConfig', (dict,), {}))
 
 
 def _load(dotted, relpath):
@@ -91,6 +96,7 @@ def load_reference_p2p():
     """attention_store / ptp_utils / seq_aligner / spatial_blend / attention_util of the reference, verbatim."""
     load_reference_models()
     base = 'videoswap/utils/p2p_utils'
+    _load('videoswap.utils.edlora_util', 'videoswap/utils/edlora_util.py')
     out = {}
     for name in ('attention_store', 'seq_aligner', 'ptp_utils', 'spatial_blend', 'attention_util'):
         out[name] = _load(f'videoswap.utils.p2p_utils.{name}', f'{base}/{name}.py')

@@ -1,0 +1,81 @@
+"""SparsePointAdapter (videoswap/models/adapter_model.py:50-136) on the libvsx kernels.
+
+Per level l: feat = MLP_l(point_embedding) [P, C_l] (two GEMMs + SiLU), then every visible point of every
+frame is splatted onto the 4 bilinear corners of the level's [F, h_l, w_l, C_l] map by ONE scatter kernel per
+level (the reference runs levels x points x frames python iterations with 4 tiny index-adds each).  Maps are
+returned channels-last and tagged `.vsx_nhwc = True` so the UNet adds them without a layout conversion;
+`.to_reference_layout()` gives the reference's [F, C, h, w].
+"""
+from typing import List
+
+import torch
+from torch import nn
+
+from . import ops
+from .compat import MODEL_REGISTRY, ConfigMixin, ModelMixin, register_to_config
+from .layers import Linear
+
+
+class _SiLU(nn.Module):
+    def forward(self, x):
+        return ops.silu(x)
+
+
+class MLP(nn.Module):
+    """adapter_model.py:12-22 — nn.Sequential(Linear, SiLU, Linear) under the attribute name `mlp`."""
+
+    def __init__(self, in_dim, out_dim, mid_dim=128):
+        super().__init__()
+        self.mlp = nn.Sequential(Linear(in_dim, mid_dim, bias=True), _SiLU(), Linear(mid_dim, out_dim, bias=True))
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+def _tag_nhwc(t):
+    t.vsx_nhwc = True
+    return t
+
+
+@MODEL_REGISTRY.register()
+class SparsePointAdapter(ModelMixin, ConfigMixin):
+
+    @register_to_config
+    def __init__(self, embedding_channels=1280, channels=[320, 640, 1280, 1280], downsample_rate=[8, 16, 32, 64],
+                 mid_dim=128):
+        super().__init__()
+        self.model_list = nn.ModuleList([MLP(embedding_channels, ch, mid_dim) for ch in channels])
+        self.downsample_rate = list(downsample_rate)
+        self.channels = list(channels)
+        self.radius = 2
+
+    @torch.no_grad()
+    def forward(self, point_tracker, size, point_embedding, index_list=None, drop_rate=0.0,
+                loss_type='global', scale=1.0) -> List[torch.Tensor]:
+        """point_tracker [1?, F, P, 2] pixel (x, y), negative = invisible; size = (W, H); point_embedding
+        [1?, P, 1280]; index_list: point ids to keep (None = all).  Returns 4 channels-last maps [F, h, w, C]."""
+        if self.training:
+            raise NotImplementedError('adapter training (loss mask / point dropout) is outside the denoising path')
+        tracks = point_tracker.squeeze(0) if point_tracker.dim() == 4 else point_tracker
+        emb = point_embedding.squeeze(0) if point_embedding.dim() == 3 else point_embedding
+        w, h = size
+        num_frames, num_points = tracks.shape[:2]
+        selected = torch.zeros(num_points, dtype=torch.int32)
+        for p in range(num_points):
+            if index_list is None or p in index_list:
+                selected[p] = 1
+        selected = selected.to(emb.device)
+        # the reference holds the tracks in the latent dtype (fp16): quantise, then hand fp32 to the kernel
+        tracks32 = tracks.to(device=emb.device).to(emb.dtype).float().contiguous()
+        emb = emb.contiguous()
+        out = []
+        for level, module in enumerate(self.model_list):
+            rate = self.downsample_rate[level]
+            feat = module(emb)                                           # [P, C_l]
+            state = ops.adapter_scatter(tracks32, selected, feat, h // rate, w // rate, float(rate), float(scale))
+            out.append(_tag_nhwc(state))
+        return out
+
+    @staticmethod
+    def to_reference_layout(states):
+        return [s.permute(0, 3, 1, 2).contiguous() for s in states]

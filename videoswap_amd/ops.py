@@ -40,7 +40,21 @@ def round_up(x, m):
 # --------------------------------------------------------------------------------------------
 # GEMM family
 # --------------------------------------------------------------------------------------------
+class FlopCounter:
+    """Algorithmic FLOP (2 x MAC, true dimensions, no padding) of the MFMA kernels launched while enabled."""
+    enabled = False
+    gemm = 0.0
+    attention = 0.0
+
+    @classmethod
+    def reset(cls, enabled=True):
+        cls.enabled, cls.gemm, cls.attention = enabled, 0.0, 0.0
+
+
 def gemm(desc):
+    if FlopCounter.enabled:
+        cols = desc.N * (2 if desc.geglu else 1)
+        FlopCounter.gemm += 2.0 * desc.M * cols * desc.K * desc.batch0 * desc.batch1
     check(_lib.load().vsx_gemm_f16(ctypes.byref(desc), _stream()), 'vsx_gemm_f16')
 
 
@@ -226,6 +240,8 @@ def attention(q, k, vt, heads, scale, kv_div=1, nk=None):
     nk = k.shape[1] if nk is None else nk
     dh = C // heads
     out = torch.empty_like(q)
+    if FlopCounter.enabled:
+        FlopCounter.attention += 4.0 * nb * heads * nq * nk * dh
     check(_lib.load().vsx_attention_f16(_p(q), _p(k), _p(vt), _p(out), nb, heads, nq, nk, dh, C, C, vt.shape[2], C,
                                         nq * C, k.shape[1] * C, C * vt.shape[2], nq * C, kv_div, float(scale),
                                         _stream()), 'vsx_attention_f16')
@@ -237,6 +253,8 @@ def temporal_attention(q, k, v, B, fq, fk, hw, heads, scale):
     _chk(q, 'q'); _chk(k, 'k'); _chk(v, 'v')
     C = q.shape[-1]
     out = torch.empty_like(q)
+    if FlopCounter.enabled:
+        FlopCounter.attention += 4.0 * B * hw * fq * fk * C
     check(_lib.load().vsx_temporal_attention_f16(_p(q), _p(k), _p(v), _p(out), B, fq, fk, hw, heads, C // heads, C, C,
                                                  C, float(scale), _stream()), 'vsx_temporal_attention_f16')
     return out
