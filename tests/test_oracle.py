@@ -136,3 +136,71 @@ def test_ops_refuse_cpu_tensors():
     from videoswap_amd._lib import VsxError
     with pytest.raises(VsxError):
         ops.linear(torch.zeros(8, 8, dtype=torch.float16), torch.zeros(8, 8, dtype=torch.float16))
+
+
+def test_oracle_adapter_equals_reference_code_verbatim():
+    from oracle import adapter, ref_import
+    if not ref_import.available():
+        pytest.skip('/root/reference is not present on this machine')
+    ref_import.load_reference_models()
+    ref_import._load('videoswap.utils.registry', 'videoswap/utils/registry.py')
+    ra = ref_import._load('videoswap.models.adapter_model', 'videoswap/models/adapter_model.py')
+    chans = [64, 128, 256, 256]
+    r = ra.SparsePointAdapter(embedding_channels=1280, channels=chans).eval()
+    o = adapter.SparsePointAdapter(1280, chans).eval()
+    o.load_state_dict(r.state_dict(), strict=True)
+    g = torch.Generator().manual_seed(0)
+    W, H = 192, 128
+    tr = torch.rand(1, 3, 6, 2, generator=g) * torch.tensor([float(W), float(H)])
+    tr[0, 0, 1] = -1
+    tr[0, 1, 2] = torch.tensor([W - 0.5, H - 0.5])
+    emb = torch.randn(1, 6, 1280, generator=g)
+    with torch.no_grad():
+        a, b = r(tr, (W, H), emb, index_list=[0, 1, 2, 4]), o(tr, (W, H), emb, index_list=[0, 1, 2, 4])
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_product_adapter_has_reference_state_dict_keys():
+    from oracle import adapter
+    from videoswap_amd.adapter import SparsePointAdapter
+    p, o = SparsePointAdapter(), adapter.SparsePointAdapter()
+    assert list(p.state_dict().keys()) == list(o.state_dict().keys())
+    assert p.config.downsample_rate == [8, 16, 32, 64]
+
+
+def test_lora_merge_matches_reference_formula():
+    """W' = W + alpha * up @ down on exactly the keys of convert_edlora_to_diffusers.py:46-53, conv weights via the
+    squeezed 1x1 factors; restoring the snapshot brings the weights back bit-exactly."""
+    from oracle import unet3d
+    from videoswap_amd.edlora import merge_lora_into_weight
+    from videoswap_amd.unet import AnimateDiffUNet3DModel
+    cfg = unet3d.tiny_config()
+    m = AnimateDiffUNet3DModel(**cfg)
+    sd = m.state_dict()
+    g = torch.Generator().manual_seed(4)
+    lora, touched = {}, []
+    for k, w in sd.items():
+        if any(k.endswith(s) for s in ('attn2.to_q.weight', 'attn1.to_out.0.weight', 'ff.net.0.proj.weight',
+                                       'attentions.0.proj_in.weight')) and 'motion' not in k:
+            base = k[:-len('weight')]
+            out_f, in_f = w.shape[0], w.shape[1]
+            down, up = torch.randn(4, in_f, generator=g) * 0.01, torch.randn(out_f, 4, generator=g) * 0.01
+            if w.dim() == 4:
+                down, up = down[:, :, None, None], up[:, :, None, None]
+            lora[base + 'lora_down.weight'], lora[base + 'lora_up.weight'] = down, up
+            touched.append(k)
+    merged = merge_lora_into_weight(sd, lora, 'unet', alpha=0.7)
+    assert len(touched) > 10
+    for k in sd:
+        if k in touched:
+            d, u = lora[k[:-6] + 'lora_down.weight'], lora[k[:-6] + 'lora_up.weight']
+            delta = (u.squeeze() @ d.squeeze()).reshape(sd[k].shape)
+            assert torch.allclose(merged[k], sd[k] + 0.7 * delta)
+        else:
+            assert torch.equal(merged[k], sd[k])
+    import copy
+    snapshot = copy.deepcopy(sd)
+    m.load_state_dict(merged)
+    m.load_state_dict(snapshot)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), snapshot.values()))

@@ -1,0 +1,25 @@
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average / share, as text.
+
+    python tools/rocpd_summary.py gpurun_out/prof/x_results.db > profiles/rNN_kernel_stats.txt
+(rocprofv3 --kernel-trace --stats writes a rocpd database on ROCm 7.2; this is the `--stats` table in plain text.)
+"""
+import sqlite3
+import sys
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute('pragma table_info(kernels)')]
+    name_col = 'name' if 'name' in cols else 'kernel_name'
+    rows = c.execute(f'select {name_col}, count(*), sum(end - start), avg(end - start), min(end - start), '
+                     f'max(end - start) from kernels group by {name_col} order by 3 desc').fetchall()
+    total = sum(r[2] for r in rows)
+    print(f'# {path}: {sum(r[1] for r in rows)} kernel dispatches, {total / 1e6:.3f} ms of kernel time')
+    print(f'{"calls":>7s} {"total_ms":>10s} {"avg_us":>9s} {"min_us":>9s} {"max_us":>9s} {"share":>6s}  kernel')
+    for name, n, tot, avg, mn, mx in rows:
+        short = name if len(name) < 110 else name[:107] + '...'
+        print(f'{n:7d} {tot / 1e6:10.3f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * tot / total:5.1f}%  {short}')
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
