@@ -2,31 +2,40 @@
 //
 //   C[m, n] = epilogue(alpha * sum_k A[m, k] * B[n, k])
 //
-// Design (CDNA4): 256-thread workgroups = 4 wave64 in a 2x2 grid, each wave owns a
-// (BM/2)x(BN/2) sub-tile built from v_mfma_f32_32x32x16_f16 tiles with fp32 accumulators.
-// K is walked in BK=64 slabs staged HBM -> registers -> LDS with two LDS buffers and ONE
-// barrier per slab: the global loads of slab t+1 are issued before the MFMAs of slab t and are
-// written to the other LDS buffer after them.  LDS rows are padded to 72 halfs (144 B = 9
-// 16-byte slots, odd) so the ds_read_b128 fragment reads of 16 distinct rows hit 16 distinct
-// slots (conflict-free).
+// Design (CDNA4):
+//  * v_mfma_f32_32x32x16_f16, fp32 accumulators.  Workgroup = WAVES_M x WAVES_N wave64; the flagship tiles are
+//    256x320 (8 waves) and 128x320 (4 waves): every wave owns a 64x160 sub-tile (2x5 MFMA tiles, 10 MFMAs per 7
+//    fragment reads).  N = 320 divides every channel count of the SD-1.5 UNet (320/640/1280 and the 2560/5120/10240
+//    GEGLU rows), so no MFMA work is wasted on column padding and the A row-panel — the big operand — is read once
+//    per 320 output columns instead of once per 128.  128x128 / 64x128 / 64x64 tiles cover small or odd problems.
+//  * Operand staging is LDS-DMA (`buffer_load_dwordx4 ... offen lds`): no VGPR round trip, no ds_write.  A ring of
+//    NSTAGE = 4 LDS slots of BK = 32 is kept PREFETCH = 3 slabs ahead with COUNTED `s_waitcnt vmcnt(N)` and one raw
+//    `s_barrier` per slab (slab kt+3 is issued right after the barrier that retires slot (kt-1) % 4).
+//  * Buffer descriptors do the edge handling: a row's per-lane byte offset is loop-invariant, K advances in the
+//    scalar offset, and an out-of-range offset makes the hardware return zeros (M/N edges, conv zero padding).
+//  * LDS rows are 64 B (4 x 16-B slots) XOR-swizzled with (row >> 2) & 3; the DMA destination must be lane-linear,
+//    so the swizzle is applied to the SOURCE column of each lane and again when fragments are read: conflict-free
+//    ds_read_b128 (SQ_LDS_BANK_CONFLICT = 0 measured).
+//  * Workgroup ids are remapped so that each XCD (own L2) walks a contiguous range of tiles.
 //
 // The A operand has two loaders:
 //   a_mode 0: plain row-major [M, K];
-//   a_mode 1: implicit im2col of a channels-last image [nimg, H, W, C1(+C2)] for a ks x ks conv
-//             (stride 1/2, zero pad ks/2), optionally reading a half-resolution source as a
-//             nearest-2x upsample, optionally concatenating two sources on the channel axis.
-//             This removes the reference's F.interpolate tensor (resnet.py:54), torch.cat
-//             (unet_blocks.py:618) and the two rearrange copies per conv (resnet.py:14-16).
-// Epilogue: alpha, bias[n], per-image row vector (time embedding, resnet.py:172-176), residual,
-// GEGLU (h * gelu(g) with h/g column blocks interleaved per wave), transposed store (V^T for
-// the attention kernel).
+//   a_mode 1: implicit im2col of a channels-last image [nimg, H, W, C1(+C2)] for a ks x ks conv (stride 1/2, zero
+//             pad ks/2), optionally reading a half-resolution source as a nearest-2x upsample, optionally
+//             concatenating two sources on the channel axis.  This removes the reference's F.interpolate tensor
+//             (resnet.py:54), torch.cat (unet_blocks.py:618) and the two rearrange copies per conv (resnet.py:14-16).
+// Epilogue: alpha, bias[n], per-image row vector (time embedding, resnet.py:172-176), residual, GEGLU (h/g weight
+// rows interleaved 16+16 inside every 32-row MFMA tile so both halves of a column land in the same lane),
+// transposed store (V^T for the attention kernel).  Accumulators hold C^T (SWAP) so a lane owns one output row and 4
+// consecutive columns per register quad: 8-byte vector loads/stores in the epilogue.
 #include "common.h"
 #include <vector>
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int LSTR = BK + 8;  // LDS row stride in halfs
+constexpr int BK = 32;          // K slab (halfs); LDS rows are 64 B = 4 16-byte slots
+constexpr int NSTAGE = 4;       // LDS ring depth
+constexpr int PREFETCH = 3;     // slabs in flight (NSTAGE - 1)
 
 struct GemmParams {
     const half_t* A;
@@ -42,31 +51,56 @@ struct GemmParams {
     long c_rows_per_img, c_img_stride, rows_per_vec;
     int batch1;
     int a_mode, H, W, C1, C2, Ho, Wo, ks, stride, ups;
-    int geglu, c_mode, c_pack4;
+    int geglu, c_mode, c_pack4, vec4;
     int tiles_n;
+    unsigned a_bytes, a2_bytes, b_bytes;   // buffer extents (per batch slice) for the SRD bounds check
     float alpha;
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int AV = BM / 32, BV = BN / 32;  // 16-byte vectors per thread per slab
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    half_t* sA = reinterpret_cast<half_t*>(smem_raw);  // [2][BM][LSTR]
-    half_t* sB = sA + 2 * BM * LSTR;                   // [2][BN][LSTR]
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// SWAP = true : accumulators hold C^T tiles (MFMA A operand = weight rows, B operand = activation rows), so a lane owns
+//               one output row m and 4 consecutive columns per register quad -> 8-byte epilogue loads/stores.
+// SWAP = false: accumulators hold C tiles; a lane owns one column n and 4 consecutive rows -> used by the transposed
+//               (V^T) store, where rows are the contiguous axis.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmParams p) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_BLKS = BM / 16, B_BLKS = BN / 16;           // 16-row LDS-DMA blocks per operand
+    static_assert(A_BLKS % NW == 0, "A blocks must split evenly over the waves");
+    constexpr int GA = A_BLKS / NW;
+    constexpr int GB_LO = B_BLKS / NW, GB_HI = (B_BLKS + NW - 1) / NW;
+    constexpr int N_HI = B_BLKS - GB_LO * NW;                   // waves [0, N_HI) issue GB_HI B blocks, the rest GB_LO
+    constexpr int STAGE = (BM + BN) * 64;                       // bytes per ring slot
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    const int tile_n = blockIdx.x % p.tiles_n;
-    const int tile_m = blockIdx.x / p.tiles_n;
+    // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (each XCD has its own 4 MiB L2), so give
+    // every XCD a CONTIGUOUS range of the (tile_m, tile_n) space.  Bijective for any grid size; placement only affects
+    // speed, never results.
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+        const int xcd = wg & 7, local = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int tile_n = wg % p.tiles_n;
+    const int tile_m = wg / p.tiles_n;
     const long m0 = (long)tile_m * BM;
-    // geglu: a BN-wide tile of B rows produces BN/2 output columns
+    // geglu: a BN-row tile of B (h and g rows interleaved) produces BN/2 output columns
     const long n0 = p.geglu ? (long)tile_n * (BN / 2) : (long)tile_n * BN;
 
     const int z = blockIdx.z;
@@ -74,211 +108,338 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const half_t* Ab = p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
     const half_t* Bb = p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
 
-    // ---- loader coordinates: thread owns column-vector lcol of rows lrow + 32*v ----
-    const int lrow = tid >> 3;
-    const int lcol = (tid & 7) * 8;
+    // ---- LDS-DMA coordinates: lane -> (row lrow of a 16-row block, physical 16-byte slot pslot) ----
+    constexpr int OOB_OFF = (int)0x80000000;
+    const int lrow = lane >> 2;
+    const int pslot = lane & 3;
+    const int kofs = (pslot ^ ((lrow >> 2) & 3)) * 8;     // this lane's k offset inside every slab
 
-    // A rows
-    bool a_ok[AV];
-    long a_off[AV];           // a_mode 0: element offset of the row
-    int a_img[AV], a_ho[AV], a_wo[AV];
-#pragma unroll
-    for (int v = 0; v < AV; ++v) {
-        const long m = m0 + lrow + 32 * v;
-        a_ok[v] = m < p.M;
-        a_off[v] = m * p.lda;
-        if (p.a_mode == 1) {
-            const long hw = (long)p.Ho * p.Wo;
-            const long mm = a_ok[v] ? m : 0;
-            a_img[v] = (int)(mm / hw);
-            const int rem = (int)(mm - (long)a_img[v] * hw);
-            a_ho[v] = rem / p.Wo;
-            a_wo[v] = rem - a_ho[v] * p.Wo;
-        } else {
-            a_img[v] = 0; a_ho[v] = 0; a_wo[v] = 0;
-        }
-    }
-    // B rows (with the GEGLU h/g interleave: 32-column blocks h0 g0 h1 g1)
-    bool b_ok[BV];
-    long b_off[BV];
-#pragma unroll
-    for (int v = 0; v < BV; ++v) {
-        const int j = lrow + 32 * v;  // row inside the tile
-        long n;
-        if (p.geglu) {
-            const int q32 = j >> 5;  // == v
-            const long oc = n0 + (q32 >> 1) * 32 + (j & 31);
-            b_ok[v] = oc < p.N;
-            n = oc + ((q32 & 1) ? p.N : 0);
-        } else {
-            n = n0 + j;
-            b_ok[v] = n < p.N;
-        }
-        b_off[v] = n * p.ldb;
-    }
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Ab), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcA2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.A2 ? p.A2 : p.A), 0, (int)p.a2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Bb), 0, (int)p.b_bytes, 0x00020000);
 
-    const int Ctot = p.C1 + p.C2;
+    bool a_ok[GA];
+    int a_h0[GA], a_w0[GA], a_ibase[GA];
+    int va[GA];                                   // current voffset of each A row (plain: fixed; conv: per tap)
     const int Hs = p.ups ? (p.H >> 1) : p.H;
     const int Ws = p.ups ? (p.W >> 1) : p.W;
     const int pad = p.ks >> 1;
-
-    uint4 ra[AV], rb[BV];
-
-    auto gload = [&](int kt) {
-        const long k = (long)kt * BK + lcol;
-        const bool kok = k < p.K;
-        if (p.a_mode == 0) {
 #pragma unroll
-            for (int v = 0; v < AV; ++v) {
-                ra[v] = (a_ok[v] && kok) ? ld16(Ab + a_off[v] + k) : make_uint4(0, 0, 0, 0);
-            }
+    for (int i = 0; i < GA; ++i) {
+        const long m = m0 + (wave * GA + i) * 16 + lrow;
+        a_ok[i] = m < p.M;
+        a_h0[i] = 0; a_w0[i] = 0; a_ibase[i] = 0;
+        va[i] = a_ok[i] ? (int)((m * p.lda + kofs) * 2) : OOB_OFF;
+        if (p.a_mode == 1) {
+            const long hw = (long)p.Ho * p.Wo;
+            const long mm = a_ok[i] ? m : 0;
+            const int img = (int)(mm / hw);
+            const int rem = (int)(mm - (long)img * hw);
+            const int ho = rem / p.Wo;
+            a_h0[i] = ho * p.stride - pad;
+            a_w0[i] = (rem - ho * p.Wo) * p.stride - pad;
+            a_ibase[i] = img * Hs;
+        }
+    }
+    // this wave's B blocks: [b_blk0, b_blk0 + gbw)
+    const int gbw = wave < N_HI ? GB_HI : GB_LO;
+    const int b_blk0 = wave < N_HI ? wave * GB_HI : N_HI * GB_HI + (wave - N_HI) * GB_LO;
+    int vb[GB_HI];
+#pragma unroll
+    for (int j = 0; j < GB_HI; ++j) {
+        const int jr = (b_blk0 + j) * 16 + lrow;      // row inside the B tile
+        long n;
+        bool ok;
+        if (p.geglu) {   // inside every 32-row MFMA tile: rows 0-15 = h columns, rows 16-31 = the matching g columns
+            const long oc = n0 + (jr >> 5) * 16 + (jr & 15);
+            ok = oc < p.N;
+            n = oc + ((jr & 16) ? p.N : 0);
         } else {
-            const int kk = kok ? (int)k : 0;
-            const int tap = kk / Ctot;
-            const int ci = kk - tap * Ctot;
-            const int kh = tap / p.ks;
-            const int kw = tap - kh * p.ks;
-            const bool second = ci >= p.C1;
-            const half_t* src = second ? p.A2 : p.A;
-            const int cs = second ? p.C2 : p.C1;
-            const int cc = second ? ci - p.C1 : ci;
+            n = n0 + jr;
+            ok = n < p.N;
+        }
+        vb[j] = (ok && j < gbw) ? (int)((n * p.ldb + kofs) * 2) : OOB_OFF;
+    }
+
+    const int Ctot = p.C1 + p.C2;
+    const int nk = (int)((p.K + BK - 1) / BK);
+    const bool ktail_lane = (long)(nk - 1) * BK + kofs >= p.K;      // only possible when K % 32 != 0
+    // conv fast path: a K slab never straddles a filter tap or the two concatenated sources, so (kh, kw, source,
+    // channel base) are wave-uniform running counters and the row offsets change only when the tap does
+    const bool fast_tap = p.a_mode == 1 && (Ctot % BK == 0) && (p.C1 % BK == 0);
+    int t_kh = 0, t_kw = 0, t_c = 0;          // state of the NEXT slab to issue (slabs are issued in order)
+    bool t_second = false, t_dirty = true;
+
+    auto issue = [&](int kt, int stage) {
+        unsigned char* sb = smem + stage * STAGE;
+        const bool last_tail = (kt == nk - 1) && ktail_lane;
+        int soffA = kt * (BK * 2);
+        bool second = false;
+        if (p.a_mode == 1) {
+            if (fast_tap) {
+                if (t_dirty) {
+                    const int cs = t_second ? p.C2 : p.C1;
 #pragma unroll
-            for (int v = 0; v < AV; ++v) {
-                const int hh = a_ho[v] * p.stride + kh - pad;
-                const int ww = a_wo[v] * p.stride + kw - pad;
-                const bool ok = a_ok[v] && kok && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W;
-                const int hsrc = p.ups ? (hh >> 1) : hh;
-                const int wsrc = p.ups ? (ww >> 1) : ww;
-                const long pix = ((long)a_img[v] * Hs + hsrc) * Ws + wsrc;
-                ra[v] = ok ? ld16(src + pix * cs + cc) : make_uint4(0, 0, 0, 0);
+                    for (int i = 0; i < GA; ++i) {
+                        const int hh = a_h0[i] + t_kh, ww = a_w0[i] + t_kw;
+                        const bool ok = a_ok[i] && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W;
+                        const int hsrc = p.ups ? (hh >> 1) : hh, wsrc = p.ups ? (ww >> 1) : ww;
+                        va[i] = ok ? (((a_ibase[i] + hsrc) * Ws + wsrc) * cs + kofs) * 2 : OOB_OFF;
+                    }
+                    t_dirty = false;
+                }
+                second = t_second;
+                soffA = t_c * 2;
+                t_c += BK;
+                if (t_c >= (t_second ? p.C2 : p.C1)) {          // next source or next tap
+                    t_c = 0;
+                    t_dirty = true;
+                    if (!t_second && p.C2 > 0) {
+                        t_second = true;
+                    } else {
+                        t_second = false;
+                        if (++t_kw == p.ks) { t_kw = 0; ++t_kh; }
+                    }
+                }
+            } else {           // generic path (conv_in: 8 padded input channels): per-lane tap decode, single source
+                const long k = (long)kt * BK + kofs;
+                const int kk = k < p.K ? (int)k : 0;
+                const int tap = kk / Ctot;
+                const int ci = kk - tap * Ctot;
+                const int kh = tap / p.ks, kw = tap - kh * p.ks;
+#pragma unroll
+                for (int i = 0; i < GA; ++i) {
+                    const int hh = a_h0[i] + kh, ww = a_w0[i] + kw;
+                    const bool ok = a_ok[i] && k < p.K && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W;
+                    const int hsrc = p.ups ? (hh >> 1) : hh, wsrc = p.ups ? (ww >> 1) : ww;
+                    va[i] = ok ? (((a_ibase[i] + hsrc) * Ws + wsrc) * p.C1 + ci) * 2 : OOB_OFF;
+                }
+                soffA = 0;
             }
         }
 #pragma unroll
-        for (int v = 0; v < BV; ++v) {
-            rb[v] = (b_ok[v] && kok) ? ld16(Bb + b_off[v] + k) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < GA; ++i) {
+            const int v = last_tail ? OOB_OFF : va[i];
+            lptr_t dst = (lptr_t)(sb + (wave * GA + i) * 1024);
+            if (second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, dst, 16, v, soffA, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, soffA, 0, 0);
+        }
+        const int soffB = kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < GB_HI; ++j) {
+            if (j < gbw) {   // wave-uniform
+                const int v = last_tail ? OOB_OFF : vb[j];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(sb + BM * 64 + (b_blk0 + j) * 1024), 16, v,
+                                                         soffB, 0, 0);
+            }
         }
     };
-    auto lstore = [&](int buf) {
-        half_t* a = sA + buf * BM * LSTR;
-        half_t* b = sB + buf * BN * LSTR;
-#pragma unroll
-        for (int v = 0; v < AV; ++v) st16(a + (lrow + 32 * v) * LSTR + lcol, ra[v]);
-#pragma unroll
-        for (int v = 0; v < BV; ++v) st16(b + (lrow + 32 * v) * LSTR + lcol, rb[v]);
-    };
 
-    f16v acc[TM][TN];
+    constexpr int NACC = SWAP ? TN : TM, MACC = SWAP ? TM : TN;
+    f16v acc[NACC][MACC];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < MACC; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (int)((p.K + BK - 1) / BK);
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    // fragment read offsets: row (.. + l31) * 64 B, logical slot ks*2 + hi, swizzled by (l31 >> 2) & 3
+    const int swz = (l31 >> 2) & 3;
+    const int a_row = (wr * WM + l31) * 64;
+    const int b_row = BM * 64 + (wc * WN + l31) * 64;
+    const int off0 = ((0 * 2 + hi) ^ swz) * 16;
+    const int off1 = ((1 * 2 + hi) ^ swz) * 16;
+
+#pragma unroll
+    for (int s = 0; s < PREFETCH; ++s)
+        if (s < nk) issue(s, s);
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more = (kt + 1) < nk;
-        if (more) gload(kt + 1);
+        // slab kt must have landed; later slabs (at most PREFETCH-1 of them) stay in flight
+        const int later = min(nk - 1 - kt, PREFETCH - 1);
+        if (wave < N_HI) {
+            constexpr int G = GA + GB_HI;
+            if (later >= 2) wait_vmcnt<2 * G>(); else if (later == 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+        } else {
+            constexpr int G = GA + GB_LO;
+            if (later >= 2) wait_vmcnt<2 * G>(); else if (later == 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();   // everybody's part of slab kt is in LDS; slot (kt-1)%NSTAGE is free
+        if (kt + PREFETCH < nk) issue(kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
 
-        const half_t* a = sA + buf * BM * LSTR + (wr * WM + l31) * LSTR + hi * 8;
-        const half_t* b = sB + buf * BN * LSTR + (wc * WN + l31) * LSTR + hi * 8;
+        const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = ks ? off1 : off0;
             h8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const h8*>(a + i * 32 * LSTR + ks * 16);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8*>(sb + a_row + i * 2048 + off);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const h8*>(b + j * 32 * LSTR + ks * 16);
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8*>(sb + b_row + j * 2048 + off);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (SWAP)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[j][i], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
         }
-        if (more) lstore(buf ^ 1);
-        __syncthreads();
     }
 
-    // ---------------- epilogue ----------------
-    // lane holds, for tile (i,j): column n = l31, rows (r&3) + 8*(r>>2) + 4*hi, r = 0..15
+    // ---------------- epilogue (32-bit element offsets: the host guarantees M*ldc, M*ldr < 2^31) ----------------
     half_t* Cb = p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
     const half_t* Rb = p.residual ? p.residual + z0 * p.r_bs0 + z1 * p.r_bs1 : nullptr;
+    const int Mi = (int)p.M, Ni = (int)p.N;
+    const int ldc = (int)p.ldc, ldr = (int)p.ldr;
+    const int mb = (int)m0, nb0 = (int)n0;
 
-    if (p.geglu) {
-        if constexpr (TN == 2) {
-            const long n = n0 + wc * 32 + l31;  // output column
-            if (n < p.N) {
-                const float bh = p.bias ? (float)p.bias[n] : 0.f;
-                const float bg = p.bias ? (float)p.bias[p.N + n] : 0.f;
+    if constexpr (SWAP) {
+        // lane owns row m (column of the C^T tile); register quad g of tile (j, i) holds 4 consecutive columns
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
+            const int m = mb + wr * WM + i * 32 + l31;
+            if (m >= Mi) continue;
+            half_t* crow = Cb + (unsigned)m * (unsigned)ldc;
+            const half_t* rrow = Rb ? Rb + (unsigned)m * (unsigned)ldr : nullptr;
+            const half_t* rv = p.rowvec ? p.rowvec + ((unsigned)m / (unsigned)p.rows_per_vec) * (unsigned)Ni : nullptr;
+            if (p.geglu) {
+                // tile j: registers 0-7 are h of 16 output columns, registers 8-15 the matching g
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const long m = m0 + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (m < p.M) {
-                            const float hval = acc[i][0][r] * p.alpha + bh;
-                            const float gval = acc[i][1][r] * p.alpha + bg;
-                            float o = hval * gelu_erf_f(gval);
-                            if (Rb) o += (float)Rb[m * p.ldr + n];
-                            Cb[m * p.ldc + n] = (half_t)o;
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int nb = nb0 + (wc * TN + j) * 16 + 8 * q + 4 * hi;
+                        if (nb >= Ni) continue;
+                        float hv[4], gv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hv[e] = acc[j][i][4 * q + e] * p.alpha;
+                            gv[e] = acc[j][i][8 + 4 * q + e] * p.alpha;
+                        }
+                        if (p.vec4 && nb + 3 < Ni) {
+                            if (p.bias) {
+                                const h4 bh = *reinterpret_cast<const h4*>(p.bias + nb);
+                                const h4 bg = *reinterpret_cast<const h4*>(p.bias + Ni + nb);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { hv[e] += (float)bh[e]; gv[e] += (float)bg[e]; }
+                            }
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
+                            if (rrow) {
+                                const h4 b = *reinterpret_cast<const h4*>(rrow + nb);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
+                            }
+                            h4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pk[e] = (half_t)o[e];
+                            *reinterpret_cast<h4*>(crow + nb) = pk;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int n = nb + e;
+                                if (n < Ni) {
+                                    const float bh = p.bias ? (float)p.bias[n] : 0.f;
+                                    const float bg = p.bias ? (float)p.bias[Ni + n] : 0.f;
+                                    float o = (hv[e] + bh) * gelu_erf_f(gv[e] + bg);
+                                    if (rrow) o += (float)rrow[n];
+                                    crow[n] = (half_t)o;
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the 40 register quads from being processed at once
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = nb0 + wc * WN + j * 32 + 8 * g + 4 * hi;
+                    if (nb >= Ni) continue;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[j][i][4 * g + e] * p.alpha;
+                    if (p.vec4 && nb + 3 < Ni) {
+                        if (p.bias) {
+                            const h4 b = *reinterpret_cast<const h4*>(p.bias + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
+                        }
+                        if (rv) {
+                            const h4 b = *reinterpret_cast<const h4*>(rv + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
+                        }
+                        if (rrow) {
+                            const h4 b = *reinterpret_cast<const h4*>(rrow + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
+                        }
+                        h4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (half_t)o[e];
+                        *reinterpret_cast<h4*>(crow + nb) = pk;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int n = nb + e;
+                            if (n < Ni) {
+                                float v = o[e];
+                                if (p.bias) v += (float)p.bias[n];
+                                if (rv) v += (float)rv[n];
+                                if (rrow) v += (float)rrow[n];
+                                crow[n] = (half_t)v;
+                            }
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // bound the live range of the epilogue's loads (no spills)
             }
         }
-        return;
-    }
-
+    } else {
+        // transposed store: lane owns column n, register quad g of tile (i, j) holds rows mg..mg+3
+        const unsigned rpi = (unsigned)p.c_rows_per_img;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const long n = n0 + wc * WN + j * 32 + l31;
-        const bool nok = n < p.N;
-        const float bv = (nok && p.bias) ? (float)p.bias[n] : 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int n = nb0 + wc * WN + j * 32 + l31;
+            if (n >= Ni) continue;
+            const float bv = p.bias ? (float)p.bias[n] : 0.f;
+            half_t* ccol = Cb + (long)n * p.ldc;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long mbase = m0 + wr * WM + i * 32 + 4 * hi;
-            if (p.c_mode == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (nok && m < p.M) {
-                        float o = acc[i][j][r] * p.alpha + bv;
-                        if (p.rowvec) o += (float)p.rowvec[(m / p.rows_per_vec) * p.N + n];
-                        if (Rb) o += (float)Rb[m * p.ldr + n];
-                        Cb[m * p.ldc + n] = (half_t)o;
-                    }
-                }
-            } else {
-                // transposed store: C[img][n][m % rows]
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const long mg = mbase + 8 * g;  // 4 consecutive rows mg..mg+3
-                    if (!nok || mg >= p.M) continue;
+                    const int mg = mb + wr * WM + i * 32 + 8 * g + 4 * hi;
+                    if (mg >= Mi) continue;
                     float o[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = acc[i][j][4 * g + q] * p.alpha + bv;
-                    if (p.c_pack4 && mg + 3 < p.M) {
-                        const long img = mg / p.c_rows_per_img;
-                        const long mm = mg - img * p.c_rows_per_img;
+                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * p.alpha + bv;
+                    if (p.c_pack4 && mg + 3 < Mi) {
+                        const unsigned img = (unsigned)mg / rpi;
+                        const unsigned mm = (unsigned)mg - img * rpi;
                         h4 pk;
-                        pk[0] = (half_t)o[0]; pk[1] = (half_t)o[1];
-                        pk[2] = (half_t)o[2]; pk[3] = (half_t)o[3];
-                        *reinterpret_cast<h4*>(Cb + img * p.c_img_stride + n * p.ldc + mm) = pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (half_t)o[e];
+                        *reinterpret_cast<h4*>(ccol + (long)img * p.c_img_stride + mm) = pk;
                     } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const long m = mg + q;
-                            if (m < p.M) {
-                                const long img = m / p.c_rows_per_img;
-                                const long mm = m - img * p.c_rows_per_img;
-                                Cb[img * p.c_img_stride + n * p.ldc + mm] = (half_t)o[q];
+                        for (int e = 0; e < 4; ++e) {
+                            const int m = mg + e;
+                            if (m < Mi) {
+                                const unsigned img = (unsigned)m / rpi;
+                                const unsigned mm = (unsigned)m - img * rpi;
+                                ccol[(long)img * p.c_img_stride + mm] = (half_t)o[e];
                             }
                         }
                     }
@@ -288,19 +449,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP>
 int launch(const GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
-    constexpr size_t smem = 2 * (BM + BN) * LSTR * sizeof(half_t);
+    constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * 64;
+    static_assert(smem <= 160 * 1024, "LDS ring exceeds 160 KiB");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WAVES_M, WAVES_N, SWAP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)nbatch);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN>), grid, dim3(256), smem, stream, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, SWAP>), grid, dim3(WAVES_M * WAVES_N * 64), smem, stream,
+                       p);
     return vsx_check_launch("vsx_gemm_f16");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_tile(GemmParams& p, long M, long cols, long nbatch, hipStream_t stream) {
+    p.tiles_n = (int)((cols + BN - 1) / BN);
+    const long tiles_m = (M + BM - 1) / BM;
+    return p.c_mode == 1 ? launch<BM, BN, WAVES_M, WAVES_N, false>(p, tiles_m, nbatch, stream)
+                         : launch<BM, BN, WAVES_M, WAVES_N, true>(p, tiles_m, nbatch, stream);
 }
 
 // ---- instrumentation (bench.py roofline): hipEvent pairs around sampled launches ----
@@ -381,10 +552,23 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     p.c_img_stride = d->c_img_stride;
 
     const long nbatch = d->batch0 * d->batch1;
+    VSX_REQUIRE(d->M < (1L << 31) && d->N < (1L << 30) && d->M * d->ldc < (1L << 31) &&
+                    (!d->residual || d->M * d->ldr < (1L << 31)),
+                VSX_E_UNSUPPORTED, "gemm: M*ldc and M*ldr must be below 2^31 elements");
+    {
+        const long brows = p.geglu ? 2 * d->N : d->N;
+        const long bb = ((brows - 1) * d->ldb + d->K) * 2;
+        VSX_REQUIRE(bb < (1L << 31), VSX_E_UNSUPPORTED, "gemm: B operand slice must be smaller than 2 GiB");
+        p.b_bytes = (unsigned)bb;
+    }
     VSX_REQUIRE(nbatch <= 65535, VSX_E_BADSHAPE, "gemm: batch0*batch1 = %ld exceeds 65535", nbatch);
 
     if (p.a_mode == 0) {
         VSX_REQUIRE(d->lda % 8 == 0, VSX_E_BADSHAPE, "gemm: lda (%ld) must be a multiple of 8", (long)d->lda);
+        const long ab = ((d->M - 1) * d->lda + d->K) * 2;
+        VSX_REQUIRE(ab < (1L << 31), VSX_E_UNSUPPORTED, "gemm: A operand slice must be smaller than 2 GiB");
+        p.a_bytes = (unsigned)ab;
+        p.a2_bytes = 0;
     } else if (p.a_mode == 1) {
         VSX_REQUIRE(nbatch == 1, VSX_E_UNSUPPORTED, "gemm: conv mode does not take a batch");
         VSX_REQUIRE(d->ks == 1 || d->ks == 3, VSX_E_UNSUPPORTED, "gemm: conv kernel size %ld", (long)d->ks);
@@ -394,6 +578,8 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
         VSX_REQUIRE((d->C2 == 0) == (d->A2 == nullptr), VSX_E_BADSHAPE, "gemm: A2/C2 mismatch");
         VSX_REQUIRE(d->A2 == nullptr || vsx_aligned16(d->A2), VSX_E_BADSHAPE, "gemm: A2 must be 16-byte aligned");
         VSX_REQUIRE(d->K == d->ks * d->ks * (d->C1 + d->C2), VSX_E_BADSHAPE, "gemm: conv K mismatch");
+        VSX_REQUIRE(d->C2 == 0 || (d->C1 % 32 == 0 && d->C2 % 32 == 0), VSX_E_UNSUPPORTED,
+                    "gemm: a two-source conv needs both channel counts to be multiples of 32");
         VSX_REQUIRE(d->H > 0 && d->W > 0, VSX_E_BADSHAPE, "gemm: conv H/W");
         VSX_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), VSX_E_BADSHAPE, "gemm: upsample needs even H/W");
         p.H = (int)d->H; p.W = (int)d->W; p.C1 = (int)d->C1; p.C2 = (int)d->C2;
@@ -401,6 +587,13 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
         const int pad = p.ks / 2;
         p.Ho = (p.H + 2 * pad - p.ks) / p.stride + 1;
         p.Wo = (p.W + 2 * pad - p.ks) / p.stride + 1;
+        {
+            const long pix = (d->M / ((long)p.Ho * p.Wo)) * (long)(p.ups ? p.H / 2 : p.H) * (p.ups ? p.W / 2 : p.W);
+            VSX_REQUIRE(pix * d->C1 * 2 < (1L << 31) && pix * d->C2 * 2 < (1L << 31), VSX_E_UNSUPPORTED,
+                        "gemm: conv source tensors must be smaller than 2 GiB");
+            p.a_bytes = (unsigned)(pix * d->C1 * 2);
+            p.a2_bytes = (unsigned)(pix * d->C2 * 2);
+        }
         VSX_REQUIRE(d->M % ((long)p.Ho * p.Wo) == 0, VSX_E_BADSHAPE, "gemm: conv M (%ld) not a multiple of Ho*Wo (%d*%d)",
                     (long)d->M, p.Ho, p.Wo);
     } else {
@@ -413,10 +606,17 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
                      d->c_bs0 % 4 == 0 && d->c_bs1 % 4 == 0) ? 1 : 0;
     }
     if (p.geglu) VSX_REQUIRE(!d->rowvec, VSX_E_UNSUPPORTED, "gemm: geglu with rowvec");
+    // 8-byte vector epilogue when every row start / column quad is 8-byte aligned
+    auto al8 = [](const void* q) { return (((uintptr_t)q) & 7) == 0; };
+    p.vec4 = (d->ldc % 4 == 0 && d->c_bs0 % 4 == 0 && d->c_bs1 % 4 == 0 && al8(d->C) && al8(d->bias) &&
+              al8(d->rowvec) && d->N % 4 == 0 &&
+              (!d->residual || (al8(d->residual) && d->ldr % 4 == 0 && d->r_bs0 % 4 == 0 && d->r_bs1 % 4 == 0)))
+                 ? 1 : 0;
 
-    // tile selection: big tiles when they still fill the 256 CUs (2 workgroups per CU)
+    // tile selection.  cols = rows of B.  The 320-wide tiles need cols % 320 == 0 (no column padding waste) and
+    // enough workgroups to cover the 256 CUs; otherwise fall back to the 128/64 tiles (2 workgroups per CU).
     const long cols = p.geglu ? 2 * d->N : d->N;
-    const long big = ((d->M + 127) / 128) * ((cols + 127) / 128) * nbatch;
+    auto blocks = [&](long bm, long bn) { return ((d->M + bm - 1) / bm) * ((cols + bn - 1) / bn) * nbatch; };
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool sample = g_prof.on && g_prof.n < g_prof.max_samples;
@@ -430,23 +630,20 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
         }
         e0 = (*g_prof.ev)[2 * g_prof.n];
         e1 = (*g_prof.ev)[2 * g_prof.n + 1];
-        hipEventRecord(e0, stream);
+        (void)hipEventRecord(e0, stream);
     }
-    if (big >= 512 || p.geglu) {
-        const bool tall = big >= 512;
-        if (tall) {
-            p.tiles_n = (int)((cols + 127) / 128);
-            rc = launch<128, 128>(p, (d->M + 127) / 128, nbatch, stream);
-        } else {
-            p.tiles_n = (int)((cols + 127) / 128);
-            rc = launch<64, 128>(p, (d->M + 63) / 64, nbatch, stream);
-        }
+    const bool wide = (cols % 320 == 0);
+    if (wide && blocks(128, 320) >= 200) {
+        rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);    // 8 waves, 32x160 per wave
+    } else if (blocks(128, 128) >= 512) {
+        rc = launch_tile<128, 128, 2, 2>(p, d->M, cols, nbatch, stream);
+    } else if (blocks(64, 128) >= 512 || (p.geglu && cols >= 128)) {
+        rc = launch_tile<64, 128, 2, 2>(p, d->M, cols, nbatch, stream);
     } else {
-        p.tiles_n = (int)((cols + 63) / 64);
-        rc = launch<64, 64>(p, (d->M + 63) / 64, nbatch, stream);
+        rc = launch_tile<64, 64, 2, 2>(p, d->M, cols, nbatch, stream);
     }
     if (sample) {
-        hipEventRecord(e1, stream);
+        (void)hipEventRecord(e1, stream);
         g_prof.n += 1;
         g_prof.flop += 2.0 * (double)d->M * (double)cols * (double)d->K * (double)nbatch;
     }
