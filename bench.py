@@ -130,10 +130,8 @@ def main():
     n_launch, gemm_ms, gemm_flop = ops.prof_collect()
     ops.prof_enable(False, 0)
 
-    if distributed:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    from videoswap_amd.distributed import max_over_ranks
+    elapsed = max_over_ranks(elapsed, device)        # whole-job time = slowest rank
 
     frames_total = world * args.steps * args.frames
     value = frames_total / elapsed

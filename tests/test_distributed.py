@@ -1,0 +1,101 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: clip sharding / timing reduction, and the two exchange
+steps of the frame-sharded long-clip mode checked against single-process math (GroupNorm over all frames from
+all-gathered partial sums; temporal attention from all-gathered K/V with global positional encoding)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _run(fn, world=2):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    results = [q.get() for _ in range(world)]
+    for p in procs:
+        assert p.exitcode == 0
+    errs = [r for r in results if isinstance(r, str)]
+    assert not errs, errs
+    return results
+
+
+def _entry(fn, rank, world, port, q):
+    import traceback
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    try:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        q.put(fn(rank, world))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        q.put(traceback.format_exc())
+        raise
+
+
+def _clip_parallel(rank, world):
+    from videoswap_amd.distributed import max_over_ranks, shard_clips
+    mine = shard_clips(7, rank, world)
+    slow = max_over_ranks(1.0 + rank)
+    return (mine, slow)
+
+
+def test_clip_parallel_bookkeeping():
+    res = _run(_clip_parallel)
+    clips = sorted(c for mine, _ in res for c in mine)
+    assert clips == list(range(7))                       # every clip exactly once, no collective on the data path
+    assert all(abs(t - 2.0) < 1e-9 for _, t in res)      # whole-job time = slowest rank
+
+
+def _frame_shard(rank, world):
+    import torch.nn.functional as F
+    from videoswap_amd.distributed import FrameShard
+    torch.manual_seed(0)                                  # same full tensors on every rank
+    B, T, HW, C, G = 2, 8, 6, 32, 8
+    shard = FrameShard(T)
+    x = torch.randn(B, T, HW, C)
+    mine = x[:, shard.frame_offset:shard.frame_offset + shard.local_frames]
+    # --- 5-D GroupNorm statistics from all-gathered partial sums (what vsx_groupnorm_stats/apply exchange) ---
+    xs = mine.reshape(B, -1, G, C // G)
+    partial = torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], -1)[:, None]            # [B, 1 chunk, G, 2]
+    allp = shard.gn_hook(partial.contiguous())
+    assert allp.shape == (B, world, G, 2)
+    tot = allp.sum(1)
+    n = T * HW * (C // G)
+    mean = tot[..., 0] / n
+    var = tot[..., 1] / n - mean * mean
+    ref = F.group_norm(x.reshape(B, T * HW, C).transpose(1, 2), G).transpose(1, 2).reshape(B, T, HW, C)
+    got = ((mine.reshape(B, -1, G, C // G) - mean[:, None, :, None]) / torch.sqrt(var[:, None, :, None] + 1e-5))
+    gn_err = (got.reshape(mine.shape) - ref[:, shard.frame_offset:shard.frame_offset + shard.local_frames]).abs().max()
+    # --- temporal attention over ALL frames from all-gathered K/V ---
+    q, k, v = torch.randn(B, T, HW, C), torch.randn(B, T, HW, C), torch.randn(B, T, HW, C)
+    sl = slice(shard.frame_offset, shard.frame_offset + shard.local_frames)
+    kg, vg, fk = shard.kv_gather(k[:, sl].reshape(-1, HW, C), v[:, sl].reshape(-1, HW, C), B, shard.local_frames, HW)
+    assert fk == T and torch.equal(kg.view(B, T, HW, C), k) and torch.equal(vg.view(B, T, HW, C), v)
+
+    def attn(qq, kk, vv):     # [B, f, HW, C] attention across the frame axis at every site
+        s = torch.einsum('bfsc,bgsc->bsfg', qq, kk) / C ** 0.5
+        return torch.einsum('bsfg,bgsc->bfsc', s.softmax(-1), vv)
+    at_err = (attn(q[:, sl], kg.view(B, T, HW, C), vg.view(B, T, HW, C)) - attn(q, k, v)[:, sl]).abs().max()
+    lat = torch.randn(1, 4, T, 3, 3)
+    full = shard.gather_frames(shard.local_slice(lat))
+    return (float(gn_err), float(at_err), bool(torch.equal(full, lat)), shard.frame_offset)
+
+
+def test_frame_shard_exchange_steps():
+    res = _run(_frame_shard)
+    for gn_err, at_err, ok, off in res:
+        assert gn_err < 1e-4 and at_err < 1e-5 and ok
+    assert sorted(r[3] for r in res) == [0, 4]
