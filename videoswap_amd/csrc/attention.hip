@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     constexpr int DK = (D + 15) / 16;   // k-steps of the QK^T product
     constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T
     constexpr int KSTR = DK * 16 + 8;
+    constexpr bool HAS_SPARE = (DT * 32 > D);   // a padding row of the O^T tile can carry the softmax denominator
 
     __shared__ __attribute__((aligned(16))) half_t sK[KV_TILE * KSTR];
     __shared__ __attribute__((aligned(16))) half_t sV[DT * 32 * VSTR];
@@ -90,6 +91,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
             st16(sK + row * KSTR + d0, v);
         }
         // ---- stage V^T tile: DT*32 rows x 8 vectors of 8 keys ----
+        // When the head dim leaves spare rows in the last 32-row tile (d = 40, 80, ...), row D is set to ones for
+        // the valid keys: O^T[D][q] then accumulates sum_k P[k][q] — the softmax denominator comes out of the MFMA
+        // (rescaled together with O) instead of 32 VALU adds + a cross-lane exchange per tile.
         for (int i = tid; i < DT * 32 * 8; i += 256) {
             const int row = i >> 3;
             const int c8 = (i & 7) * 8;
@@ -102,6 +106,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
                     for (int e = 0; e < 8; ++e)
                         if (key0 + e >= p.nk) v[e] = (half_t)0.f;
                 }
+            } else if (HAS_SPARE && row == D) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (key0 + e < p.nk) ? (half_t)1.f : (half_t)0.f;
             }
             const uint4 u = as_u4(v);
             uint2* dst = reinterpret_cast<uint2*>(sV + row * VSTR + c8);
@@ -123,37 +130,44 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
                 s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t], s[kt], 0, 0, 0);
             }
         }
-        // ---- online softmax (lane-local per query column) ----
-        float mx = -INFINITY;
+        // ---- online softmax (lane-local per query column); VALU budget: max3, fma, exp2, cvt per score ----
+        if (j0 + KV_TILE > p.nk) {   // only the last, partial key tile needs masking (wave-uniform branch)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = j0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float x = s[kt][r] * p.scale_log2e;
-                if (key >= p.nk) x = -INFINITY;
-                s[kt][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_i, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = j0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= p.nk) s[kt][r] = -INFINITY;
+                }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2e;      // scale > 0: max commutes with the scaling
+        if (!__all(mx <= m_i)) {     // running max grows: rescale O (and the denominator row inside it)
+            const float m_new = fmaxf(m_i, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+            m_i = m_new;
+            if (!HAS_SPARE) l_i *= alpha;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
+        const float neg_m = -m_i;
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], p.scale_log2e, neg_m));
                 s[kt][r] = e;
-                rs += e;
+                if (!HAS_SPARE) rs += e;
             }
-        rs += __shfl_xor(rs, 32, 64);
-        l_i = l_i * alpha + rs;
-        m_i = m_new;
-#pragma unroll
-        for (int t = 0; t < DT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        if (!HAS_SPARE) {
+            rs += __shfl_xor(rs, 32, 64);
+            l_i += rs;
+        }
 
         // ---- O^T += V^T P^T ----
         // B operand k-slot jj of (kt, s2) on lane hi carries key kt*32 + 16*s2 + 8*(jj>>2) + 4*hi + (jj&3)
@@ -177,6 +191,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
                 }
             }
         }
+    }
+
+    if (HAS_SPARE) {
+        // the denominator sits in row D of O^T: tile D/32, register ((D%32)>>3)*4 + (D&3) of the lanes with
+        // hi == ((D%32)>>2)&1; broadcast it to the lane pair
+        constexpr int DR = D % 32;
+        constexpr int reg = (DR >> 3) * 4 + (DR & 3);
+        constexpr int owner_hi = (DR >> 2) & 1;
+        const float mine = o[D / 32][reg];
+        const float other = __shfl_xor(mine, 32, 64);
+        l_i = (hi == owner_hi) ? mine : other;
     }
 
     // ---- normalise and store: lane (q, hi) holds O[q, t*32 + 8*g + 4*hi + 0..3] ----
