@@ -34,21 +34,31 @@ struct AttnParams {
 };
 
 constexpr int KV_TILE = 64;
-constexpr int VSTR = 68;
+constexpr int VSTR = 72;          // V^T LDS row: 64 keys + one 16-byte dummy slot (odd slot count)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int D>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     constexpr int DK = (D + 15) / 16;   // k-steps of the QK^T product
     constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T
-    constexpr int KSTR = DK * 16 + 8;
+    constexpr int KSTR = DK * 16 + 8;   // K LDS row (halfs): 2*DK real/zero slots + one dummy slot (odd slot count)
     constexpr bool HAS_SPARE = (DT * 32 > D);   // a padding row of the O^T tile can carry the softmax denominator
+    constexpr int KSPR = KSTR / 8, VSPR = VSTR / 8;              // 16-byte slots per LDS row
+    constexpr int K_UNITS = KV_TILE * KSPR, V_UNITS = D * VSPR;  // 16-byte units per tile (V: rows < D only)
+    constexpr int NKI = (K_UNITS + 255) / 256, NVI = (V_UNITS + 255) / 256;   // LDS-DMA instructions per wave
+    constexpr int K_BYTES = KV_TILE * KSTR * 2;
+    constexpr int V_BYTES = DT * 32 * VSTR * 2;
+    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int OOB_OFF = (int)0x80000000;
 
-    __shared__ __attribute__((aligned(16))) half_t sK[KV_TILE * KSTR];
-    __shared__ __attribute__((aligned(16))) half_t sV[DT * 32 * VSTR];
+    // two-slot LDS ring filled by LDS-DMA (`buffer_load_dwordx4 ... lds`): tile j+1 streams in while tile j is
+    // consumed; per-lane offsets are loop-invariant, the key position advances in the scalar offset, out-of-range
+    // rows / pad slots read as zero through the buffer descriptor
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y;
     const long b = blockIdx.z;
@@ -68,6 +78,67 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         }
     }
 
+    const half_t* Kb = p.K + kvb * p.k_bs + h * D;
+    const half_t* Vb = p.VT + kvb * p.vt_bs + (long)h * D * p.ldvt;
+    const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(Kb), 0, (int)((((long)p.nk - 1) * p.ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(Vb), 0, (int)((long)D * p.ldvt * 2), 0x00020000);
+    int vk[NKI], vv[NVI];
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+        const int u = (wave * NKI + i) * 64 + lane;
+        const int row = u / KSPR, slot = u - row * KSPR;
+        vk[i] = (u < K_UNITS && slot * 8 < D) ? (int)(((long)row * p.ldk + slot * 8) * 2) : OOB_OFF;
+    }
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+        const int u = (wave * NVI + i) * 64 + lane;
+        const int row = u / VSPR, slot = u - row * VSPR;
+        vv[i] = (u < V_UNITS && slot < 8) ? (int)(((long)row * p.ldvt + slot * 8) * 2) : OOB_OFF;
+    }
+    // rows >= D of the V^T tiles are never written by the DMA: zero them once, and put the ones row in place
+    for (int i = tid; i < 2 * (DT * 32 - D) * VSTR; i += 256) {
+        const int st = i / ((DT * 32 - D) * VSTR), r = i - st * ((DT * 32 - D) * VSTR);
+        const int row = D + r / VSTR, col = r - (r / VSTR) * VSTR;
+        half_t* sv = reinterpret_cast<half_t*>(smem + st * STAGE + K_BYTES);
+        // the ones row is the LAST row of the tile: the tail lanes of the final V^T DMA instruction write zeros into
+        // the (up to 7) rows right after row D-1, so row D itself is not safe
+        sv[row * VSTR + col] = (HAS_SPARE && row == DT * 32 - 1 && col < KV_TILE) ? (half_t)1.f : (half_t)0.f;
+    }
+
+    auto issue = [&](int j0, int stage) {
+        unsigned char* sb = smem + stage * STAGE;
+        const int soffK = (int)((long)j0 * p.ldk * 2);
+        const int soffV = j0 * 2;
+        // the descriptor's range check does not cover the scalar offset: in the last, partial tile the rows / key
+        // slots past the end are switched off per lane (once per workgroup)
+        const bool partial = j0 + KV_TILE > p.nk;
+#pragma unroll
+        for (int i = 0; i < NKI; ++i)
+            if ((wave * NKI + i) * 64 < K_UNITS) {     // wave-uniform
+                int v = vk[i];
+                if (partial && j0 + ((wave * NKI + i) * 64 + lane) / KSPR >= p.nk) v = OOB_OFF;
+                // lanes past the end of the tile are switched off (EXEC): a DMA lane always writes its 16 bytes,
+                // zeros included, and would clobber the neighbouring LDS region
+                if ((wave * NKI + i) * 64 + lane < K_UNITS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, (lds_ptr_t)(sb + (wave * NKI + i) * 1024), 16, v,
+                                                             soffK, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < NVI; ++i)
+            if ((wave * NVI + i) * 64 < V_UNITS) {
+                int v = vv[i];
+                if (partial) {
+                    const int u = (wave * NVI + i) * 64 + lane;
+                    if (j0 + (u - (u / VSPR) * VSPR) * 8 >= p.ldvt) v = OOB_OFF;
+                }
+                if ((wave * NVI + i) * 64 + lane < V_UNITS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, (lds_ptr_t)(sb + K_BYTES + (wave * NVI + i) * 1024),
+                                                             16, v, soffV, 0, 0);
+            }
+    };
+
     f16v o[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t)
@@ -76,46 +147,14 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     float m_i = -INFINITY;
     float l_i = 0.f;
 
-    const half_t* Kb = p.K + kvb * p.k_bs + h * D;
-    const half_t* Vb = p.VT + kvb * p.vt_bs + (long)h * D * p.ldvt;
-
-    for (int j0 = 0; j0 < p.nk; j0 += KV_TILE) {
-        __syncthreads();  // previous tile fully consumed
-        // ---- stage K tile: 64 rows x DK*2 vectors ----
-        for (int i = tid; i < KV_TILE * DK * 2; i += 256) {
-            const int row = i / (DK * 2);
-            const int d0 = (i - row * (DK * 2)) * 8;
-            const int key = j0 + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (key < p.nk && d0 < D) v = ld16(Kb + (long)key * p.ldk + d0);
-            st16(sK + row * KSTR + d0, v);
-        }
-        // ---- stage V^T tile: DT*32 rows x 8 vectors of 8 keys ----
-        // When the head dim leaves spare rows in the last 32-row tile (d = 40, 80, ...), row D is set to ones for
-        // the valid keys: O^T[D][q] then accumulates sum_k P[k][q] — the softmax denominator comes out of the MFMA
-        // (rescaled together with O) instead of 32 VALU adds + a cross-lane exchange per tile.
-        for (int i = tid; i < DT * 32 * 8; i += 256) {
-            const int row = i >> 3;
-            const int c8 = (i & 7) * 8;
-            const int key0 = j0 + c8;
-            h8 v = as_h8(make_uint4(0, 0, 0, 0));
-            if (row < D && key0 < p.nk) {
-                v = as_h8(ld16(Vb + (long)row * p.ldvt + key0));
-                if (key0 + 8 > p.nk) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (key0 + e >= p.nk) v[e] = (half_t)0.f;
-                }
-            } else if (HAS_SPARE && row == D) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (key0 + e < p.nk) ? (half_t)1.f : (half_t)0.f;
-            }
-            const uint4 u = as_u4(v);
-            uint2* dst = reinterpret_cast<uint2*>(sV + row * VSTR + c8);
-            dst[0] = make_uint2(u.x, u.y);
-            dst[1] = make_uint2(u.z, u.w);
-        }
-        __syncthreads();
+    issue(0, 0);
+    int stage = 0;
+    for (int j0 = 0; j0 < p.nk; j0 += KV_TILE, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // tile j0 is in LDS for every wave; the other slot is no longer being read
+        if (j0 + KV_TILE < p.nk) issue(j0 + KV_TILE, stage ^ 1);
+        const half_t* sK = reinterpret_cast<const half_t*>(smem + stage * STAGE);
+        const half_t* sV = reinterpret_cast<const half_t*>(smem + stage * STAGE + K_BYTES);
 
         // ---- S^T = K Q^T : two 32-key row tiles ----
         f16v s[2];
@@ -194,12 +233,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     }
 
     if (HAS_SPARE) {
-        // the denominator sits in row D of O^T: tile D/32, register ((D%32)>>3)*4 + (D&3) of the lanes with
-        // hi == ((D%32)>>2)&1; broadcast it to the lane pair
-        constexpr int DR = D % 32;
-        constexpr int reg = (DR >> 3) * 4 + (DR & 3);
-        constexpr int owner_hi = (DR >> 2) & 1;
-        const float mine = o[D / 32][reg];
+        // the denominator sits in the last row (31) of the last O^T tile: register 15 of the lanes with hi == 1;
+        // broadcast it to the lane pair
+        constexpr int reg = 15;
+        constexpr int owner_hi = 1;
+        const float mine = o[DT - 1][reg];
         const float other = __shfl_xor(mine, 32, 64);
         l_i = (hi == owner_hi) ? mine : other;
     }

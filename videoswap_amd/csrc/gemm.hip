@@ -635,6 +635,8 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     const bool wide = (cols % 320 == 0);
     if (wide && blocks(128, 320) >= 200) {
         rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);    // 8 waves, 32x160 per wave
+    } else if (cols % 160 == 0 && blocks(128, 160) >= 200) {
+        rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);    // 4 waves, 32x160 per wave, 2 WG per CU
     } else if (blocks(128, 128) >= 512) {
         rc = launch_tile<128, 128, 2, 2>(p, d->M, cols, nbatch, stream);
     } else if (blocks(64, 128) >= 512 || (p.geglu && cols >= 128)) {

@@ -6,9 +6,19 @@
 namespace {
 
 constexpr int GN_STAT_THREADS = 512;
-constexpr int GN_STAT_ROWS = 256;   // rows per statistics chunk
-constexpr int GN_APPLY_ROWS = 32;   // rows per apply block
 constexpr int GN_MAX_GROUPS = 64;
+
+// rows per statistics chunk / per apply block: sized so that even the 8x8 and 16x16 levels (1-4 K rows per image)
+// spread over >= 128 workgroups per image instead of 4 (the low-resolution GroupNorms were latency-, not
+// bandwidth-bound), while the 64x64 level keeps long sequential streams
+__host__ __device__ inline int gn_stat_rows(long rows) {
+    long r = rows / 256;
+    return (int)(r < 8 ? 8 : (r > 256 ? 256 : r));
+}
+__host__ __device__ inline int gn_apply_rows(long rows) {
+    long r = rows / 512;
+    return (int)(r < 2 ? 2 : (r > 32 ? 32 : r));
+}
 
 __device__ __forceinline__ uint4 gn_load(const half_t* x1, const half_t* x2, long row, int c, int C1, int C2) {
     return (c < C1) ? ld16(x1 + row * C1 + c) : ld16(x2 + row * C2 + (c - C1));
@@ -28,8 +38,9 @@ __global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t*
     const int cv = tid - rl * vpr;
     const int chunk = blockIdx.x;
     const long img = blockIdx.y;
-    const long r0 = (long)chunk * GN_STAT_ROWS;
-    const long r1 = min(r0 + (long)GN_STAT_ROWS, rows);
+    const int rpc = gn_stat_rows(rows);
+    const long r0 = (long)chunk * rpc;
+    const long r1 = min(r0 + (long)rpc, rows);
 
     float s[8], q[8];
 #pragma unroll
@@ -80,22 +91,37 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     const int cpg = C / groups;
     const int tid = threadIdx.x;
     const long img = blockIdx.y;
-    if (tid < groups) {
+    // reduce the per-chunk partial sums: 256 threads = (256/groups) chunk subsets x groups, then a fixed-order
+    // combine in LDS (deterministic; identical on every workgroup and every rank)
+    __shared__ float s_part[256][2];
+    {
+        const int nsub = 256 / groups;                  // groups <= 64 -> nsub >= 4
+        const int g = tid % groups, sub = tid / groups;
         float a = 0.f, b = 0.f;
-        const float* pp = partial + (img * nchunks * groups + tid) * 2;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            a += pp[(long)ch * groups * 2];
-            b += pp[(long)ch * groups * 2 + 1];
+        if (sub < nsub) {
+            const float* pp = partial + (img * nchunks * groups + g) * 2;
+            for (int ch = sub; ch < nchunks; ch += nsub) {
+                a += pp[(long)ch * groups * 2];
+                b += pp[(long)ch * groups * 2 + 1];
+            }
         }
-        const float mean = a * inv_count;
-        const float var = fmaxf(b * inv_count - mean * mean, 0.f);
-        s_mean[tid] = mean;
-        s_rstd[tid] = rsqrtf(var + eps);
+        s_part[tid][0] = a;
+        s_part[tid][1] = b;
+        __syncthreads();
+        if (tid < groups) {
+            float sa = 0.f, sb = 0.f;
+            for (int k = 0; k < nsub; ++k) { sa += s_part[k * groups + tid][0]; sb += s_part[k * groups + tid][1]; }
+            const float mean = sa * inv_count;
+            const float var = fmaxf(sb * inv_count - mean * mean, 0.f);
+            s_mean[tid] = mean;
+            s_rstd[tid] = rsqrtf(var + eps);
+        }
     }
     __syncthreads();
     const int vpr = C >> 3;
-    const long r0 = (long)blockIdx.x * GN_APPLY_ROWS;
-    const long nrow = min((long)GN_APPLY_ROWS, rows - r0);
+    const int rpb = gn_apply_rows(rows);
+    const long r0 = (long)blockIdx.x * rpb;
+    const long nrow = min((long)rpb, rows - r0);
     const long nvec = nrow * vpr;
     for (long i = tid; i < nvec; i += 256) {
         const long r = i / vpr;
@@ -195,7 +221,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ 
 
 }  // namespace
 
-extern "C" int64_t vsx_groupnorm_chunks(int64_t rows) { return (rows + GN_STAT_ROWS - 1) / GN_STAT_ROWS; }
+extern "C" int64_t vsx_groupnorm_chunks(int64_t rows) {
+    const int rpc = gn_stat_rows(rows);
+    return (rows + rpc - 1) / rpc;
+}
 
 static int gn_check(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1, int64_t C2,
                     int64_t groups) {
@@ -235,7 +264,8 @@ extern "C" int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg,
                 "groupnorm_apply: gamma/beta/y must be 16-byte aligned");
     const int64_t C = C1 + C2;
     const float inv_count = 1.0f / ((float)count_rows * (float)(C / groups));
-    dim3 grid((unsigned)((rows + GN_APPLY_ROWS - 1) / GN_APPLY_ROWS), (unsigned)nimg);
+    const int rpb = gn_apply_rows(rows);
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nimg);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
                        (long)rows, (int)C1, (int)C2, (int)groups, partial, (int)nchunks, inv_count,
                        (const half_t*)gamma, (const half_t*)beta, eps, (int)silu, (half_t*)y);
