@@ -60,11 +60,21 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y;
-    const long b = blockIdx.z;
+    // XCD-aware order (1-D grid): workgroup id b lands on XCD b % 8; give every XCD a contiguous range of
+    // (image, head, query-tile) so the query tiles that share one head's K / V^T stream them from the same L2
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7;
+        const int xcd = wg & 7, local = wg >> 3;
+        wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + local;
+    }
+    const int qtiles = (p.nq + 127) / 128;
+    const int qt = wg % qtiles;
+    const int h = (wg / qtiles) % p.heads;
+    const long b = wg / (qtiles * p.heads);
     const long kvb = b / p.kv_div;
 
-    const int q = blockIdx.x * 128 + wave * 32 + l31;
+    const int q = qt * 128 + wave * 32 + l31;
     const bool qok = q < p.nq;
 
     // Q fragments: B operand of S^T = K Q^T; lane (q, hi) holds Q[q, t*16 + hi*8 .. +7]
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 
 template <int D>
 int launch_attn(const AttnParams& p, long nb, hipStream_t stream) {
-    dim3 grid((unsigned)((p.nq + 127) / 128), (unsigned)p.heads, (unsigned)nb);
+    dim3 grid((unsigned)(((p.nq + 127) / 128) * (long)p.heads * nb));
     hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), 0, stream, p);
     return vsx_check_launch("vsx_attention_f16");
 }
