@@ -34,8 +34,9 @@
 namespace {
 
 constexpr int BK = 32;          // K slab (halfs); LDS rows are 64 B = 4 16-byte slots
-constexpr int NSTAGE = 4;       // LDS ring depth
-constexpr int PREFETCH = 3;     // slabs in flight (NSTAGE - 1)
+// LDS ring depth NSTAGE is a template parameter: 4 slots (3 slabs in flight) for long K loops; 2 slots for short ones
+// (K <= 640), where halving the LDS footprint lets two workgroups share a CU and overlap one's prologue / epilogue
+// with the other's main loop — the dominant cost when the loop is only 10-20 slabs long
 
 struct GemmParams {
     const half_t* A;
@@ -68,8 +69,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 //               one output row m and 4 consecutive columns per register quad -> 8-byte epilogue loads/stores.
 // SWAP = false: accumulators hold C tiles; a lane owns one column n and 4 consecutive rows -> used by the transposed
 //               (V^T) store, where rows are the contiguous axis.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP, int NSTAGE>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmParams p) {
+    constexpr int PREFETCH = NSTAGE - 1;
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -265,10 +267,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         const int later = min(nk - 1 - kt, PREFETCH - 1);
         if (wave < N_HI) {
             constexpr int G = GA + GB_HI;
-            if (later >= 2) wait_vmcnt<2 * G>(); else if (later == 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+            if (PREFETCH >= 3 && later >= 2) wait_vmcnt<2 * G>();
+            else if (PREFETCH >= 2 && later == 1) wait_vmcnt<G>();
+            else wait_vmcnt<0>();
         } else {
             constexpr int G = GA + GB_LO;
-            if (later >= 2) wait_vmcnt<2 * G>(); else if (later == 1) wait_vmcnt<G>(); else wait_vmcnt<0>();
+            if (PREFETCH >= 3 && later >= 2) wait_vmcnt<2 * G>();
+            else if (PREFETCH >= 2 && later == 1) wait_vmcnt<G>();
+            else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();   // everybody's part of slab kt is in LDS; slot (kt-1)%NSTAGE is free
         if (kt + PREFETCH < nk) issue(kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
@@ -449,20 +455,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP, int NSTAGE>
 int launch(const GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
     constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * 64;
     static_assert(smem <= 160 * 1024, "LDS ring exceeds 160 KiB");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WAVES_M, WAVES_N, SWAP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WAVES_M, WAVES_N, SWAP, NSTAGE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)nbatch);
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, SWAP>), grid, dim3(WAVES_M * WAVES_N * 64), smem, stream,
-                       p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, SWAP, NSTAGE>), grid, dim3(WAVES_M * WAVES_N * 64), smem,
+                       stream, p);
     return vsx_check_launch("vsx_gemm_f16");
 }
 
@@ -470,8 +476,10 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_tile(GemmParams& p, long M, long cols, long nbatch, hipStream_t stream) {
     p.tiles_n = (int)((cols + BN - 1) / BN);
     const long tiles_m = (M + BM - 1) / BM;
-    return p.c_mode == 1 ? launch<BM, BN, WAVES_M, WAVES_N, false>(p, tiles_m, nbatch, stream)
-                         : launch<BM, BN, WAVES_M, WAVES_N, true>(p, tiles_m, nbatch, stream);
+    if (p.c_mode == 1) return launch<BM, BN, WAVES_M, WAVES_N, false, 4>(p, tiles_m, nbatch, stream);
+    // measured: the 2-slot ring pays for the epilogue-heavy GEGLU (+15-20 %), not for the memory-bound plain GEMMs
+    if (p.geglu && p.K <= 640) return launch<BM, BN, WAVES_M, WAVES_N, true, 2>(p, tiles_m, nbatch, stream);
+    return launch<BM, BN, WAVES_M, WAVES_N, true, 4>(p, tiles_m, nbatch, stream);
 }
 
 // ---- instrumentation (bench.py roofline): hipEvent pairs around sampled launches ----
