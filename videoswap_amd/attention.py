@@ -52,6 +52,19 @@ class Attention(nn.Module):
         self.to_out = nn.ModuleList([Linear(inner_dim, query_dim, bias=out_bias), Identity()])
         self.set_processor(processor if processor is not None else AttnProcessor2_0())
 
+    def fused_weight(self, names):
+        """Row-concatenation of the projection weights in `names` (e.g. ('to_q', 'to_k')) so that projections of the
+        same input run as ONE GEMM (the input panel is streamed once).  Cached; rebuilt when any of the parameters
+        changes (LoRA merge / load_state_dict bump `_version`, .to()/.half() replace the storage)."""
+        ws = [getattr(self, n).weight for n in names]
+        key = tuple((w.data_ptr(), w._version, w.dtype) for w in ws)
+        cache = self.__dict__.setdefault('_fused_cache', {})
+        hit = cache.get(names)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([w.detach() for w in ws], dim=0).contiguous())
+            cache[names] = hit
+        return hit[1]
+
     def set_processor(self, processor):
         if (hasattr(self, 'processor') and isinstance(self.processor, nn.Module)
                 and not isinstance(processor, nn.Module)):
@@ -129,8 +142,17 @@ class _FusedProcessor:
         if attention_mask is not None:
             raise NotImplementedError('attention masks are never used on the VideoSwap path')
         nb = hidden_states.shape[0]
-        q = attn.to_q(hidden_states)
-        k, vt, nk = _project_kv(attn, hidden_states, encoder_hidden_states, self.cross_attention_idx)
+        if encoder_hidden_states is None and attn.to_q.bias is None and attn.to_k.bias is None:
+            # self-attention: q and k in one GEMM ([.., 2C] buffer, consumed as column slices), V^T separately
+            c = attn.to_q.out_features
+            qk = ops.linear(hidden_states, attn.fused_weight(('to_q', 'to_k')))
+            q, k = qk[..., :c], qk[..., c:]
+            nk = hidden_states.shape[1]
+            vt = ops.linear_vt(hidden_states.reshape(nb * nk, hidden_states.shape[-1]), attn.to_v.weight,
+                               attn.to_v.bias, nk)
+        else:
+            q = attn.to_q(hidden_states)
+            k, vt, nk = _project_kv(attn, hidden_states, encoder_hidden_states, self.cross_attention_idx)
         kv_div = nb // k.shape[0]
         o = ops.attention(q, k, vt, attn.heads, attn.scale, kv_div=kv_div, nk=nk)
         if attn.residual_connection:
@@ -253,12 +275,14 @@ class VanillaAttentionProcessor(nn.Module):
         if self.pos_encoder is not None and not pe_applied:
             pe = self.pe_table()[self.frame_offset:self.frame_offset + frames].to(x.dtype)
             x = (x.view(b, frames, hw, c) + pe[None, :, None, :]).view(bf, hw, c)
-        q = attn.to_q(x)
-        k = attn.to_k(x)
-        v = attn.to_v(x)
+        if attn.to_q.bias is None and attn.to_k.bias is None and attn.to_v.bias is None:
+            qkv = ops.linear(x, attn.fused_weight(('to_q', 'to_k', 'to_v'))).view(-1, 3 * c)   # one GEMM, N = 3C
+            q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+        else:
+            q, k, v = attn.to_q(x).view(-1, c), attn.to_k(x).view(-1, c), attn.to_v(x).view(-1, c)
         fk = frames
         if self.kv_gather is not None:
-            k, v, fk = self.kv_gather(k, v, b, frames, hw)
-        o = ops.temporal_attention(q.view(-1, c), k.view(-1, c), v.view(-1, c), b, frames, fk, hw, attn.heads,
-                                   attn.scale).view(bf, hw, c)
+            k, v, fk = self.kv_gather(k.contiguous().view(bf, hw, c), v.contiguous().view(bf, hw, c), b, frames, hw)
+            k, v = k.view(-1, c), v.view(-1, c)
+        o = ops.temporal_attention(q, k, v, b, frames, fk, hw, attn.heads, attn.scale).view(bf, hw, c)
         return attn.to_out[0](o, residual=residual)

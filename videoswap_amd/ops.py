@@ -233,30 +233,54 @@ def attention_pv(probs, vt, kv_div=1):
     return out
 
 
+def _rows_view(t, name):
+    """[n, rows, C] tensor or column-slice view of a wider [n, rows, W] buffer (fused q|k|v projections): returns
+    (row stride, batch stride) in elements after checking what the kernels need."""
+    _chk_view(t, name)
+    if t.dim() != 3 or t.stride(2) != 1 or t.stride(1) % 8 or t.stride(0) % 8 or (t.data_ptr() % 16):
+        raise _lib.VsxError(f'{name}: need unit inner stride, 16-byte aligned base, strides multiple of 8 (got {t.stride()})')
+    return t.stride(1), t.stride(0)
+
+
+def _chk_view(t, name):
+    if not t.is_cuda or t.dtype != _F16:
+        raise _lib.VsxError(f'{name}: expected an fp16 GPU tensor')
+
+
 def attention(q, k, vt, heads, scale, kv_div=1, nk=None):
-    """Fused softmax(q k^T * scale) v.  q [nb,nq,C]; k [nkvb,nk,C]; vt [nkvb,C,ldvt] -> [nb,nq,C]."""
-    _chk(q, 'q'); _chk(k, 'k'); _chk(vt, 'vt')
+    """Fused softmax(q k^T * scale) v.  q [nb,nq,C]; k [nkvb,nk,C] (both may be column slices of a fused projection
+    buffer); vt [nkvb,C,ldvt] -> [nb,nq,C]."""
+    _chk(vt, 'vt')
+    ldq, q_bs = _rows_view(q, 'q')
+    ldk, k_bs = _rows_view(k, 'k')
     nb, nq, C = q.shape
     nk = k.shape[1] if nk is None else nk
     dh = C // heads
-    out = torch.empty_like(q)
+    out = torch.empty(nb, nq, C, dtype=_F16, device=q.device)
     if FlopCounter.enabled:
         FlopCounter.attention += 4.0 * nb * heads * nq * nk * dh
-    check(_lib.load().vsx_attention_f16(_p(q), _p(k), _p(vt), _p(out), nb, heads, nq, nk, dh, C, C, vt.shape[2], C,
-                                        nq * C, k.shape[1] * C, C * vt.shape[2], nq * C, kv_div, float(scale),
+    check(_lib.load().vsx_attention_f16(_p(q), _p(k), _p(vt), _p(out), nb, heads, nq, nk, dh, ldq, ldk, vt.shape[2], C,
+                                        q_bs, k_bs, C * vt.shape[2], nq * C, kv_div, float(scale),
                                         _stream()), 'vsx_attention_f16')
     return out
 
 
 def temporal_attention(q, k, v, B, fq, fk, hw, heads, scale):
-    """q [B*fq*hw, C], k/v [B*fk*hw, C] in (b, f, site) row order -> [B*fq*hw, C]."""
-    _chk(q, 'q'); _chk(k, 'k'); _chk(v, 'v')
+    """q [B*fq*hw, C], k/v [B*fk*hw, C] in (b, f, site) row order (possibly column slices of one fused q|k|v
+    buffer) -> [B*fq*hw, C]."""
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _chk_view(t, n)
+        if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16:
+            raise _lib.VsxError(f'{n}: need a [rows, C] tensor with unit inner stride and aligned rows')
+    if k.stride(0) != v.stride(0):
+        raise _lib.VsxError('temporal_attention: k and v must share their row stride')
     C = q.shape[-1]
-    out = torch.empty_like(q)
+    out = torch.empty(q.shape[0], C, dtype=_F16, device=q.device)
     if FlopCounter.enabled:
         FlopCounter.attention += 4.0 * B * hw * fq * fk * C
-    check(_lib.load().vsx_temporal_attention_f16(_p(q), _p(k), _p(v), _p(out), B, fq, fk, hw, heads, C // heads, C, C,
-                                                 C, float(scale), _stream()), 'vsx_temporal_attention_f16')
+    check(_lib.load().vsx_temporal_attention_f16(_p(q), _p(k), _p(v), _p(out), B, fq, fk, hw, heads, C // heads,
+                                                 q.stride(0), k.stride(0), C, float(scale), _stream()),
+          'vsx_temporal_attention_f16')
     return out
 
 
