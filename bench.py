@@ -155,9 +155,14 @@ def main():
     }
     if n_launch > 0 and gemm_ms > 0:
         ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
+        traffic = None      # HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh (same launch mix)
+        tpath = os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')
+        if os.path.exists(tpath) and args.frames == 16 and args.latent == 64:
+            with open(tpath) as f:
+                traffic = round(json.load(f)['hbm_bytes_per_launch'])
         out['roofline'] = {'bound': 'mfma', 'kernel': 'vsx_gemm_f16 (implicit-GEMM conv + GEMM, all shapes)',
                            'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                           'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                            'launches_sampled': int(n_launch),
                            'avg_launch_us': round(1000.0 * gemm_ms / n_launch, 2),
                            'avg_launch_gflop': round(gemm_flop / n_launch / 1e9, 2),
