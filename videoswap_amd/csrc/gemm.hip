@@ -30,6 +30,7 @@
 // consecutive columns per register quad: 8-byte vector loads/stores in the epilogue.
 #include "common.h"
 #include <vector>
+#include <stdlib.h>
 
 namespace {
 
@@ -641,7 +642,12 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
         (void)hipEventRecord(e0, stream);
     }
     const bool wide = (cols % 320 == 0);
-    if (wide && blocks(128, 320) >= 200) {
+    if (wide && d->K >= 640 && blocks(256, 320) >= 240) {
+        // 16 waves (1024 threads, 4 per SIMD), 32x160 per wave: 142 FLOP per staged byte — operand delivery into the
+        // CU (~7.5 TB/s aggregate measured) is what bounds these kernels, so the tile is as large as LDS allows.
+        // Short K loops (K = 320) stay on the 128-row tile: more, smaller workgroups overlap their pro/epilogues.
+        rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
+    } else if (wide && blocks(128, 320) >= 200) {
         rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);    // 8 waves, 32x160 per wave
     } else if (cols % 160 == 0 && blocks(128, 160) >= 200) {
         rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);    // 4 waves, 32x160 per wave, 2 WG per CU
