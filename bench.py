@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--latent', type=int, default=64)
     ap.add_argument('--ddim-steps', type=int, default=50)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--prof-samples', type=int, default=60000)
+    ap.add_argument('--prof-samples', type=int, default=400000)
     return ap.parse_args()
 
 
