@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 1
+#define VSX_ABI_VERSION 2
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -99,18 +99,19 @@ int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream);
  *   (resnet.py:166,177; unet.py:474: statistics pooled over frames); nimg = B*F, rows = H*W the
  *   per-frame one (attention.py:108; motion_module.py:146).
  * vsx_groupnorm_stats writes fp32 partial sums partial[img][chunk][group][2] (sum, sumsq) with
- * chunk count = vsx_groupnorm_chunks(rows); vsx_groupnorm_apply reduces them (deterministic
- * order) and writes y = (x-mean)*rstd*gamma+beta (optionally SiLU) as one [nimg, rows, C1+C2].
+ * chunk count = vsx_groupnorm_chunks(rows, nimg); vsx_groupnorm_apply reduces them (deterministic
+ * order) into stats[nimg][groups][2] = (mean, rstd) (fp32 workspace, caller-allocated) and writes
+ * y = (x-mean)*rstd*gamma+beta (optionally SiLU) as one [nimg, rows, C1+C2].
  * In frame-sharded mode the caller all-reduces `partial` between the two calls and passes the
  * GLOBAL element count in `count_rows`.
  * ------------------------------------------------------------------------------------------ */
-int64_t vsx_groupnorm_chunks(int64_t rows);
+int64_t vsx_groupnorm_chunks(int64_t rows, int64_t nimg);
 int vsx_groupnorm_stats(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
                         int64_t C2, int64_t groups, float* partial, vsx_stream_t stream);
 int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
                         int64_t C2, int64_t groups, const float* partial, int64_t nchunks,
                         int64_t count_rows, const void* gamma, const void* beta, float eps,
-                        int64_t silu, void* y, vsx_stream_t stream);
+                        int64_t silu, float* stats, void* y, vsx_stream_t stream);
 
 /* K4: LayerNorm over the last dim of x[M, C] (attention.py:182,199,205; motion_module.py:213,219).
  * If pe != NULL, adds pe[((m / rows_per_frame) % frames) + frame_offset][c] (fp16 [max_len, C]) to

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so')
 
-VSX_ABI_VERSION = 1
+VSX_ABI_VERSION = 2
 
 
 class VsxError(RuntimeError):
@@ -40,11 +40,11 @@ PROTOTYPES = {
     'vsx_abi_version': (c_int, []),
     'vsx_last_error': (c_char_p, []),
     'vsx_gemm_f16': (c_int, [POINTER(GemmDesc), c_void_p]),
-    'vsx_groupnorm_chunks': (c_int64, [c_int64]),
+    'vsx_groupnorm_chunks': (c_int64, [c_int64, c_int64]),
     'vsx_groupnorm_stats': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                     c_void_p]),
     'vsx_groupnorm_apply': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
-                                    c_int64, c_int64, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
+                                    c_int64, c_int64, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     'vsx_layernorm': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
                               c_int64, c_void_p, c_void_p]),
     'vsx_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 14 + [c_float, c_void_p]),

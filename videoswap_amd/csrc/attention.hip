@@ -412,6 +412,10 @@ extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const vo
     VSX_REQUIRE(vsx_aligned16(Q) && vsx_aligned16(K) && vsx_aligned16(V) && vsx_aligned16(O), VSX_E_BADSHAPE,
                 "temporal_attention: tensors must be 16-byte aligned");
     VSX_REQUIRE(B <= 65535 && heads <= 65535, VSX_E_BADSHAPE, "temporal_attention: grid limits");
+    TempParams p;
+    p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
+    p.fq = (int)fq; p.fk = (int)fk; p.hw = (int)hw; p.heads = (int)heads; p.d = (int)d;
+    p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.scale = scale;
     const size_t smem = (size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float);
     VSX_REQUIRE(smem <= 160 * 1024, VSX_E_UNSUPPORTED, "temporal_attention: %zu bytes of LDS needed (> 160 KiB)", smem);
     static size_t smem_attr = 64 * 1024;
@@ -421,10 +425,6 @@ extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const vo
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "temporal_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
         smem_attr = 160 * 1024;
     }
-    TempParams p;
-    p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
-    p.fq = (int)fq; p.fk = (int)fk; p.hw = (int)hw; p.heads = (int)heads; p.d = (int)d;
-    p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.scale = scale;
     dim3 grid((unsigned)hw, (unsigned)heads, (unsigned)B);
     hipLaunchKernelGGL(temporal_attn_kernel, grid, dim3(64), smem, (hipStream_t)stream, p);
     return vsx_check_launch("vsx_temporal_attention_f16");

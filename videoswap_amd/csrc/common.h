@@ -41,7 +41,8 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_exp + v_rcp (1 ulp) instead of an IEEE division: the result is rounded to fp16 anyway
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output rounding): one v_rcp, one v_exp
 // and five FMAs instead of the ~40-instruction libm erff — the GEGLU epilogue evaluates it once per output element
 __device__ __forceinline__ float erf_fast(float x) {

@@ -8,16 +8,15 @@ namespace {
 constexpr int GN_STAT_THREADS = 512;
 constexpr int GN_MAX_GROUPS = 64;
 
-// rows per statistics chunk / per apply block: sized so that even the 8x8 and 16x16 levels (1-4 K rows per image)
-// spread over >= 128 workgroups per image instead of 4 (the low-resolution GroupNorms were latency-, not
-// bandwidth-bound), while the 64x64 level keeps long sequential streams
-__host__ __device__ inline int gn_stat_rows(long rows) {
-    long r = rows / 256;
-    return (int)(r < 8 ? 8 : (r > 256 ? 256 : r));
+// rows per statistics chunk / per apply block: sized for ~2048 workgroups in total whatever the split between images
+// and rows (5-D GroupNorm: 2 images x 65536 rows; per-frame GroupNorm: 32 images x 4096 rows; 8x8 level: 1-4 K rows)
+__host__ __device__ inline int gn_stat_rows(long rows, long nimg) {
+    long r = rows * nimg / 2048;
+    return (int)(r < 8 ? 8 : (r > 512 ? 512 : r));
 }
-__host__ __device__ inline int gn_apply_rows(long rows) {
-    long r = rows / 512;
-    return (int)(r < 2 ? 2 : (r > 32 ? 32 : r));
+__host__ __device__ inline int gn_apply_rows(long rows, long nimg) {
+    long r = rows * nimg / 2048;
+    return (int)(r < 2 ? 2 : (r > 64 ? 64 : r));
 }
 
 __device__ __forceinline__ uint4 gn_load(const half_t* x1, const half_t* x2, long row, int c, int C1, int C2) {
@@ -38,7 +37,7 @@ __global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t*
     const int cv = tid - rl * vpr;
     const int chunk = blockIdx.x;
     const long img = blockIdx.y;
-    const int rpc = gn_stat_rows(rows);
+    const int rpc = gn_stat_rows(rows, gridDim.y);
     const long r0 = (long)chunk * rpc;
     const long r1 = min(r0 + (long)rpc, rows);
 
@@ -79,66 +78,91 @@ __global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t*
     }
 }
 
-// grid (ceil(rows/GN_APPLY_ROWS), nimg), block 256.
+// grid (nimg), block 256: mean / rstd of every (image, group) from the per-chunk partial sums — 256 threads =
+// (256/groups) chunk subsets x groups, then a fixed-order combine (deterministic; identical on every rank)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int groups,
+                                                          float inv_count, float eps, float* __restrict__ stats) {
+    __shared__ float s_part[256][2];
+    const int tid = threadIdx.x;
+    const long img = blockIdx.x;
+    const int nsub = 256 / groups;                  // groups <= 64 -> nsub >= 4
+    const int g = tid % groups, sub = tid / groups;
+    float a = 0.f, b = 0.f;
+    if (sub < nsub) {
+        const float* pp = partial + (img * nchunks * groups + g) * 2;
+        for (int ch = sub; ch < nchunks; ch += nsub) {
+            a += pp[(long)ch * groups * 2];
+            b += pp[(long)ch * groups * 2 + 1];
+        }
+    }
+    s_part[tid][0] = a;
+    s_part[tid][1] = b;
+    __syncthreads();
+    if (tid < groups) {
+        float sa = 0.f, sb = 0.f;
+        for (int k = 0; k < nsub; ++k) { sa += s_part[k * groups + tid][0]; sb += s_part[k * groups + tid][1]; }
+        const float mean = sa * inv_count;
+        const float var = fmaxf(sb * inv_count - mean * mean, 0.f);
+        stats[(img * groups + tid) * 2] = mean;
+        stats[(img * groups + tid) * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+// grid (ceil(rows / gn_apply_rows(rows)), nimg), block 256.  Per-channel scale/shift (a = rstd*gamma,
+// b = beta - mean*a) are built once per workgroup in LDS, so the streaming loop is one FMA (+ SiLU) per element —
+// the first version recomputed the group index with an integer division per element and was VALU-bound.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2,
                                                        long rows, int C1, int C2, int groups,
-                                                       const float* __restrict__ partial, int nchunks, float inv_count,
+                                                       const float* __restrict__ stats,
                                                        const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
-                                                       float eps, int silu, half_t* __restrict__ y) {
+                                                       int silu, half_t* __restrict__ y) {
     __shared__ float s_mean[GN_MAX_GROUPS];
     __shared__ float s_rstd[GN_MAX_GROUPS];
+    __shared__ __attribute__((aligned(16))) float s_a[4096];
+    __shared__ __attribute__((aligned(16))) float s_b[4096];
     const int C = C1 + C2;
     const int cpg = C / groups;
     const int tid = threadIdx.x;
     const long img = blockIdx.y;
-    // reduce the per-chunk partial sums: 256 threads = (256/groups) chunk subsets x groups, then a fixed-order
-    // combine in LDS (deterministic; identical on every workgroup and every rank)
-    __shared__ float s_part[256][2];
-    {
-        const int nsub = 256 / groups;                  // groups <= 64 -> nsub >= 4
-        const int g = tid % groups, sub = tid / groups;
-        float a = 0.f, b = 0.f;
-        if (sub < nsub) {
-            const float* pp = partial + (img * nchunks * groups + g) * 2;
-            for (int ch = sub; ch < nchunks; ch += nsub) {
-                a += pp[(long)ch * groups * 2];
-                b += pp[(long)ch * groups * 2 + 1];
-            }
-        }
-        s_part[tid][0] = a;
-        s_part[tid][1] = b;
-        __syncthreads();
-        if (tid < groups) {
-            float sa = 0.f, sb = 0.f;
-            for (int k = 0; k < nsub; ++k) { sa += s_part[k * groups + tid][0]; sb += s_part[k * groups + tid][1]; }
-            const float mean = sa * inv_count;
-            const float var = fmaxf(sb * inv_count - mean * mean, 0.f);
-            s_mean[tid] = mean;
-            s_rstd[tid] = rsqrtf(var + eps);
-        }
+    if (tid < groups) {
+        s_mean[tid] = stats[(img * groups + tid) * 2];
+        s_rstd[tid] = stats[(img * groups + tid) * 2 + 1];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float a = s_rstd[g] * (float)gamma[c];
+        s_a[c] = a;
+        s_b[c] = (float)beta[c] - s_mean[g] * a;
     }
     __syncthreads();
     const int vpr = C >> 3;
-    const int rpb = gn_apply_rows(rows);
+    const int rpb = gn_apply_rows(rows, gridDim.y);
     const long r0 = (long)blockIdx.x * rpb;
-    const long nrow = min((long)rpb, rows - r0);
-    const long nvec = nrow * vpr;
-    for (long i = tid; i < nvec; i += 256) {
-        const long r = i / vpr;
-        const int c = (int)(i - r * vpr) * 8;
+    const int nrow = (int)min((long)rpb, rows - r0);
+    const int nvec = nrow * vpr;
+    // vpr and 256 are both multiples of 8, or the column of a thread simply walks: recompute it cheaply per step
+    int r = tid / vpr, cv = tid - r * vpr;
+    const int dr = 256 / vpr, dc = 256 - dr * vpr;
+    for (int i = tid; i < nvec; i += 256) {
+        const int c = cv * 8;
         const long row = img * rows + r0 + r;
         const h8 v = as_h8(gn_load(x1, x2, row, c, C1, C2));
-        const h8 gm = as_h8(ld16(gamma + c));
-        const h8 bt = as_h8(ld16(beta + c));
+        const f4v a0 = *reinterpret_cast<const f4v*>(s_a + c), a1 = *reinterpret_cast<const f4v*>(s_a + c + 4);
+        const f4v b0 = *reinterpret_cast<const f4v*>(s_b + c), b1 = *reinterpret_cast<const f4v*>(s_b + c + 4);
         h8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / cpg;
-            float f = ((float)v[e] - s_mean[g]) * s_rstd[g] * (float)gm[e] + (float)bt[e];
-            if (silu) f = silu_f(f);
-            o[e] = (half_t)f;
+        for (int e = 0; e < 4; ++e) {
+            float f0 = __builtin_fmaf((float)v[e], a0[e], b0[e]);
+            float f1 = __builtin_fmaf((float)v[e + 4], a1[e], b1[e]);
+            if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
+            o[e] = (half_t)f0;
+            o[e + 4] = (half_t)f1;
         }
         st16(y + row * C + c, as_u4(o));
+        r += dr;
+        cv += dc;
+        if (cv >= vpr) { cv -= vpr; ++r; }
     }
 }
 
@@ -221,8 +245,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ 
 
 }  // namespace
 
-extern "C" int64_t vsx_groupnorm_chunks(int64_t rows) {
-    const int rpc = gn_stat_rows(rows);
+extern "C" int64_t vsx_groupnorm_chunks(int64_t rows, int64_t nimg) {
+    const int rpc = gn_stat_rows(rows, nimg);
     return (rows + rpc - 1) / rpc;
 }
 
@@ -246,7 +270,7 @@ extern "C" int vsx_groupnorm_stats(const void* x1, const void* x2, int64_t nimg,
     int rc = gn_check(x1, x2, nimg, rows, C1, C2, groups);
     if (rc) return rc;
     VSX_REQUIRE(partial != nullptr, VSX_E_WORKSPACE, "groupnorm_stats: null partial buffer");
-    dim3 grid((unsigned)vsx_groupnorm_chunks(rows), (unsigned)nimg);
+    dim3 grid((unsigned)vsx_groupnorm_chunks(rows, nimg), (unsigned)nimg);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_STAT_THREADS), 0, (hipStream_t)stream, (const half_t*)x1,
                        (const half_t*)x2, (long)rows, (int)C1, (int)C2, (int)groups, partial);
     return vsx_check_launch("vsx_groupnorm_stats");
@@ -255,20 +279,22 @@ extern "C" int vsx_groupnorm_stats(const void* x1, const void* x2, int64_t nimg,
 extern "C" int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
                                    int64_t C2, int64_t groups, const float* partial, int64_t nchunks,
                                    int64_t count_rows, const void* gamma, const void* beta, float eps, int64_t silu,
-                                   void* y, vsx_stream_t stream) {
+                                   float* stats, void* y, vsx_stream_t stream) {
     int rc = gn_check(x1, x2, nimg, rows, C1, C2, groups);
     if (rc) return rc;
-    VSX_REQUIRE(partial && gamma && beta && y, VSX_E_BADSHAPE, "groupnorm_apply: null argument");
+    VSX_REQUIRE(partial && gamma && beta && y && stats, VSX_E_BADSHAPE, "groupnorm_apply: null argument");
     VSX_REQUIRE(nchunks > 0 && count_rows > 0, VSX_E_BADSHAPE, "groupnorm_apply: nchunks/count_rows");
     VSX_REQUIRE(vsx_aligned16(gamma) && vsx_aligned16(beta) && vsx_aligned16(y), VSX_E_BADSHAPE,
                 "groupnorm_apply: gamma/beta/y must be 16-byte aligned");
     const int64_t C = C1 + C2;
     const float inv_count = 1.0f / ((float)count_rows * (float)(C / groups));
-    const int rpb = gn_apply_rows(rows);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nimg), dim3(256), 0, (hipStream_t)stream, partial,
+                       (int)nchunks, (int)groups, inv_count, eps, stats);
+    const int rpb = gn_apply_rows(rows, nimg);
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nimg);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
-                       (long)rows, (int)C1, (int)C2, (int)groups, partial, (int)nchunks, inv_count,
-                       (const half_t*)gamma, (const half_t*)beta, eps, (int)silu, (half_t*)y);
+                       (long)rows, (int)C1, (int)C2, (int)groups, stats, (const half_t*)gamma, (const half_t*)beta,
+                       (int)silu, (half_t*)y);
     return vsx_check_launch("vsx_groupnorm_apply");
 }
 

@@ -298,7 +298,7 @@ def group_norm(x, gamma, beta, groups, eps, nimg, silu=False, x2=None, partial_h
     C2 = x2.shape[-1] if x2 is not None else 0
     rows = x.numel() // C1 // nimg
     lib = _lib.load()
-    nchunks = lib.vsx_groupnorm_chunks(rows)
+    nchunks = lib.vsx_groupnorm_chunks(rows, nimg)
     partial = torch.empty(nimg, nchunks, groups, 2, dtype=torch.float32, device=x.device)
     s = _stream()
     check(lib.vsx_groupnorm_stats(_p(x), _p(x2), nimg, rows, C1, C2, groups, _p(partial), s), 'vsx_groupnorm_stats')
@@ -306,9 +306,10 @@ def group_norm(x, gamma, beta, groups, eps, nimg, silu=False, x2=None, partial_h
         partial = partial_hook(partial)
         nchunks = partial.shape[1]
     y = torch.empty(*x.shape[:-1], C1 + C2, dtype=_F16, device=x.device)
+    stats = torch.empty(nimg, groups, 2, dtype=torch.float32, device=x.device)
     check(lib.vsx_groupnorm_apply(_p(x), _p(x2), nimg, rows, C1, C2, groups, _p(partial), nchunks,
                                   rows if count_rows is None else count_rows, _p(gamma), _p(beta), float(eps),
-                                  1 if silu else 0, _p(y), s), 'vsx_groupnorm_apply')
+                                  1 if silu else 0, _p(stats), _p(y), s), 'vsx_groupnorm_apply')
     return y
 
 
