@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 2
+#define VSX_ABI_VERSION 3
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -88,9 +88,15 @@ typedef struct vsx_gemm_desc {
     int64_t geglu;        /* 1: out[m,n] = (acc_h+b_h) * gelu_erf(acc_g+b_g), h=row n, g=row N+n of B
                              (diffusers GEGLU used at attention.py:204, motion_module.py:218) */
     double alpha;
+    /* optional split-K workspace (fp32 partial sums), caller-allocated: vsx_gemm_workspace(d) bytes, or NULL.  Small-M
+       / long-K problems (the 8x8 and 16x16 UNet levels) are then sliced along K so that every CU gets a tile. */
+    void* workspace;
+    int64_t workspace_bytes;
 } vsx_gemm_desc;
 
 int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream);
+/* bytes of `workspace` that make split-K possible for this problem (0: it would not be split) */
+int64_t vsx_gemm_workspace(const vsx_gemm_desc* d);
 
 /* ------------------------------------------------------------------------------------------
  * K3: GroupNorm over channels-last activations, two kernels.

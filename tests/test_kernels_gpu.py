@@ -100,6 +100,35 @@ def test_conv2d(nimg, H, W, C1, C2, Cout, ks, stride, ups):
     assert rel_err(out, ref) < 2e-3
 
 
+@pytest.mark.parametrize('M,N,K', [(2048, 1280, 2560), (300, 640, 4096), (1024, 320, 5120)])
+def test_linear_split_k(M, N, K):
+    """small-M / long-K problems are sliced along K (fp32 partials + deterministic combine kernel)"""
+    x, w, b, r = rnd(M, K, seed=61), rnd(N, K, seed=62, scale=K ** -0.5), rnd(N, seed=63), rnd(M, N, seed=64)
+    out = ops().linear(x, w, b, residual=r)
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    assert rel_err(out, ref) < 2e-3
+    assert torch.equal(out, ops().linear(x, w, b, residual=r))       # deterministic
+
+
+@pytest.mark.parametrize('nimg,H,W,C1,C2,Cout,stride,ups', [
+    (2, 8, 8, 256, 0, 640, 1, False),        # 72 slabs -> 3 slices
+    (4, 8, 8, 128, 192, 320, 1, False),      # two sources: the tap counters start mid-way in a slice
+    (2, 16, 16, 320, 0, 320, 2, False),      # stride 2
+    (2, 4, 4, 640, 0, 640, 1, True),         # nearest-2x upsample folded in
+])
+def test_conv2d_split_k(nimg, H, W, C1, C2, Cout, stride, ups):
+    x = rnd(nimg, H, W, C1, seed=65)
+    x2 = rnd(nimg, H, W, C2, seed=66) if C2 else None
+    K = 9 * (C1 + C2)
+    w, b = rnd(Cout, 3, 3, C1 + C2, seed=67, scale=K ** -0.5), rnd(Cout, seed=68)
+    Ho = (2 * H if ups else H) // stride
+    Wo = (2 * W if ups else W) // stride
+    rowvec, res = rnd(nimg, Cout, seed=69), rnd(nimg, Ho, Wo, Cout, seed=70)
+    out = ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec, rows_per_vec=Ho * Wo, residual=res)
+    ref = conv_ref(x, w, b, stride, x2, ups) + rowvec.float()[:, None, None, :] + res.float()
+    assert rel_err(out, ref) < 2e-3
+
+
 def test_conv2d_epilogue_rowvec_residual():
     nimg, H, W, C, Cout = 4, 8, 8, 64, 128
     x, w, b = rnd(nimg, H, W, C, seed=15), rnd(Cout, 3, 3, C, seed=16, scale=(9 * C) ** -0.5), rnd(Cout, seed=17)

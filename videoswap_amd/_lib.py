@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so')
 
-VSX_ABI_VERSION = 2
+VSX_ABI_VERSION = 3
 
 
 class VsxError(RuntimeError):
@@ -32,6 +32,7 @@ class GemmDesc(Structure):
         ('bias', c_void_p), ('rowvec', c_void_p), ('rows_per_vec', c_int64),
         ('residual', c_void_p), ('ldr', c_int64), ('r_bs0', c_int64), ('r_bs1', c_int64),
         ('geglu', c_int64), ('alpha', c_double),
+        ('workspace', c_void_p), ('workspace_bytes', c_int64),
     ]
 
 
@@ -40,6 +41,7 @@ PROTOTYPES = {
     'vsx_abi_version': (c_int, []),
     'vsx_last_error': (c_char_p, []),
     'vsx_gemm_f16': (c_int, [POINTER(GemmDesc), c_void_p]),
+    'vsx_gemm_workspace': (c_int64, [POINTER(GemmDesc)]),
     'vsx_groupnorm_chunks': (c_int64, [c_int64, c_int64]),
     'vsx_groupnorm_stats': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                     c_void_p]),

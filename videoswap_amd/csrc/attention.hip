@@ -294,17 +294,22 @@ struct TempParams {
     float scale;
 };
 
-__global__ __launch_bounds__(64) void temporal_attn_kernel(const TempParams p) {
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const TempParams p) {
+    // 4 waves per workgroup, one (site, head) problem per wave (heads are split over blockIdx.y * 4 + wave); each wave
+    // has its own LDS slice, the workgroup barriers only keep the four waves in step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int d = p.d, fq = p.fq, fk = p.fk;
-    half_t* sQ = reinterpret_cast<half_t*>(smem_raw);   // [fq][d]
+    const int wave = threadIdx.x >> 6;
+    const size_t slice = (((size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float)) + 15) & ~(size_t)15;
+    unsigned char* base = smem_raw + wave * slice;
+    half_t* sQ = reinterpret_cast<half_t*>(base);        // [fq][d]
     half_t* sK = sQ + fq * d;                            // [fk][d]
     half_t* sV = sK + fk * d;                            // [fk][d]
     float* sS = reinterpret_cast<float*>(sV + fk * d);   // [fq][fk]
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const long site = blockIdx.x;
-    const int h = blockIdx.y;
+    const int h = min((int)blockIdx.y * 4 + wave, p.heads - 1);   // surplus waves redo the last head (same values)
     const long b = blockIdx.z;
     const int dv = d >> 3;
 
@@ -326,7 +331,10 @@ __global__ __launch_bounds__(64) void temporal_attn_kernel(const TempParams p) {
             const h8 a = *reinterpret_cast<const h8*>(sQ + f * d + c);
             const h8 k = *reinterpret_cast<const h8*>(sK + g * d + c);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)k[e];
+            for (int e = 0; e < 8; e += 2) {     // v_dot2_f32_f16: two fp16 products accumulated in fp32
+                const h2 a2 = {a[e], a[e + 1]}, k2 = {k[e], k[e + 1]};
+                acc = __builtin_amdgcn_fdot2(a2, k2, acc, false);
+            }
         }
         sS[i] = acc * p.scale;
     }
@@ -416,7 +424,8 @@ extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const vo
     p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
     p.fq = (int)fq; p.fk = (int)fk; p.hw = (int)hw; p.heads = (int)heads; p.d = (int)d;
     p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.scale = scale;
-    const size_t smem = (size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float);
+    const size_t slice = (((size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float)) + 15) & ~(size_t)15;
+    const size_t smem = 4 * slice;
     VSX_REQUIRE(smem <= 160 * 1024, VSX_E_UNSUPPORTED, "temporal_attention: %zu bytes of LDS needed (> 160 KiB)", smem);
     static size_t smem_attr = 64 * 1024;
     if (smem > smem_attr) {
@@ -425,7 +434,7 @@ extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const vo
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "temporal_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
         smem_attr = 160 * 1024;
     }
-    dim3 grid((unsigned)hw, (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL(temporal_attn_kernel, grid, dim3(64), smem, (hipStream_t)stream, p);
+    dim3 grid((unsigned)hw, (unsigned)((heads + 3) / 4), (unsigned)B);
+    hipLaunchKernelGGL(temporal_attn_kernel, grid, dim3(256), smem, (hipStream_t)stream, p);
     return vsx_check_launch("vsx_temporal_attention_f16");
 }

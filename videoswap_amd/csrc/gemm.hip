@@ -56,6 +56,8 @@ struct GemmParams {
     int geglu, c_mode, c_pack4, vec4;
     int tiles_n;
     unsigned a_bytes, a2_bytes, b_bytes;   // buffer extents (per batch slice) for the SRD bounds check
+    int splitk, nk_per;                    // split-K: grid.z = splitk slices of nk_per slabs, fp32 partials to `ws`
+    float* ws;
     float alpha;
 };
 
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // geglu: a BN-row tile of B (h and g rows interleaved) produces BN/2 output columns
     const long n0 = p.geglu ? (long)tile_n * (BN / 2) : (long)tile_n * BN;
 
-    const int z = blockIdx.z;
+    const int split = p.splitk > 1 ? (int)blockIdx.z : 0;
+    const int z = p.splitk > 1 ? 0 : (int)blockIdx.z;
     const int z0 = z / p.batch1, z1 = z - z0 * p.batch1;
     const half_t* Ab = p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
     const half_t* Bb = p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
@@ -173,8 +176,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // conv fast path: a K slab never straddles a filter tap or the two concatenated sources, so (kh, kw, source,
     // channel base) are wave-uniform running counters and the row offsets change only when the tap does
     const bool fast_tap = p.a_mode == 1 && (Ctot % BK == 0) && (p.C1 % BK == 0);
+    const int kt_begin = split * p.nk_per;
+    const int kt_end = p.splitk > 1 ? min(nk, kt_begin + p.nk_per) : nk;
     int t_kh = 0, t_kw = 0, t_c = 0;          // state of the NEXT slab to issue (slabs are issued in order)
     bool t_second = false, t_dirty = true;
+    if (fast_tap && kt_begin > 0) {           // split-K slice: start the running tap counters at slab kt_begin
+        const int k0 = kt_begin * BK;
+        const int tap = k0 / Ctot, rem = k0 - tap * Ctot;
+        t_kh = tap / p.ks;
+        t_kw = tap - t_kh * p.ks;
+        t_second = rem >= p.C1;
+        t_c = t_second ? rem - p.C1 : rem;
+    }
 
     auto issue = [&](int kt, int stage) {
         unsigned char* sb = smem + stage * STAGE;
@@ -259,13 +272,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     const int off0 = ((0 * 2 + hi) ^ swz) * 16;
     const int off1 = ((1 * 2 + hi) ^ swz) * 16;
 
+    const int nloc = kt_end - kt_begin;
 #pragma unroll
     for (int s = 0; s < PREFETCH; ++s)
-        if (s < nk) issue(s, s);
+        if (s < nloc) issue(kt_begin + s, s);
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < nloc; ++kt) {
         // slab kt must have landed; later slabs (at most PREFETCH-1 of them) stay in flight
-        const int later = min(nk - 1 - kt, PREFETCH - 1);
+        const int later = min(nloc - 1 - kt, PREFETCH - 1);
         if (wave < N_HI) {
             constexpr int G = GA + GB_HI;
             if (PREFETCH >= 3 && later >= 2) wait_vmcnt<2 * G>();
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             else wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();   // everybody's part of slab kt is in LDS; slot (kt-1)%NSTAGE is free
-        if (kt + PREFETCH < nk) issue(kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
+        if (kt + PREFETCH < nloc) issue(kt_begin + kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
 
         const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
 #pragma unroll
@@ -309,6 +323,28 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     const int mb = (int)m0, nb0 = (int)n0;
 
     if constexpr (SWAP) {
+        if (p.splitk > 1) {
+            // split-K slice: raw fp32 partial sums to ws[split][m][n]; vsx's reduce kernel applies the epilogue
+            float* wsl = p.ws + (size_t)split * (size_t)Mi * (size_t)Ni;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = mb + wr * WM + i * 32 + l31;
+                if (m >= Mi) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = nb0 + wc * WN + j * 32 + 8 * g + 4 * hi;
+                        if (nb + 3 < Ni) {
+                            f4v o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = acc[j][i][4 * g + e] * p.alpha;
+                            *reinterpret_cast<f4v*>(wsl + (size_t)m * Ni + nb) = o;
+                        }
+                    }
+            }
+            return;
+        }
         // lane owns row m (column of the C^T tile); register quad g of tile (j, i) holds 4 consecutive columns
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -456,6 +492,52 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     }
 }
 
+// split-K combine: out[m, n] = sum_z ws[z][m][n] + bias + rowvec + residual (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;          // one thread per 4 consecutive columns
+    const int nq = (int)(p.N >> 2);
+    if (q >= p.M * nq) return;
+    const int m = (int)(q / nq), nb = (int)(q - (long)m * nq) * 4;
+    const size_t slab = (size_t)p.M * (size_t)p.N;
+    f4v acc = *reinterpret_cast<const f4v*>(p.ws + (size_t)m * p.N + nb);
+    for (int z = 1; z < p.splitk; ++z) {
+        const f4v v = *reinterpret_cast<const f4v*>(p.ws + z * slab + (size_t)m * p.N + nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    if (p.bias) {
+        const h4 b = *reinterpret_cast<const h4*>(p.bias + nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (float)b[e];
+    }
+    if (p.rowvec) {
+        const h4 b = *reinterpret_cast<const h4*>(p.rowvec + (size_t)(m / p.rows_per_vec) * p.N + nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (float)b[e];
+    }
+    if (p.residual) {
+        const h4 b = *reinterpret_cast<const h4*>(p.residual + (size_t)m * p.ldr + nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (float)b[e];
+    }
+    h4 pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[e] = (half_t)acc[e];
+    *reinterpret_cast<h4*>(p.C + (size_t)m * p.ldc + nb) = pk;
+}
+
+// Split-K plan: small-M, long-K problems (the 8x8 / 16x16 UNet levels: M = 1-4 K rows, K up to 23 040) cannot fill
+// 256 CUs with output tiles alone; slicing K gives every CU a 128x320 tile to work on.  Returns the slice count (1 =
+// no split) for a problem whose wide tiles would number `tiles`.
+inline int plan_splitk(const vsx_gemm_desc* d, long tiles, bool eligible) {
+    if (!eligible || tiles >= 160) return 1;
+    const long nk = (d->K + BK - 1) / BK;
+    int s = (int)((256 + tiles - 1) / tiles);
+    if (s > 8) s = 8;
+    while (s > 1 && nk / s < 24) --s;     // keep >= 24 slabs per slice
+    return s;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP, int NSTAGE>
 int launch(const GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
     constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * 64;
@@ -467,7 +549,7 @@ int launch(const GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)nbatch);
+    dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)(p.splitk > 1 ? p.splitk : nbatch));
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, SWAP, NSTAGE>), grid, dim3(WAVES_M * WAVES_N * 64), smem,
                        stream, p);
     return vsx_check_launch("vsx_gemm_f16");
@@ -522,6 +604,17 @@ extern "C" int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* t
     g_prof.n = 0;
     g_prof.flop = 0.0;
     return VSX_OK;
+}
+
+extern "C" int64_t vsx_gemm_workspace(const vsx_gemm_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    const long nbatch = d->batch0 * d->batch1;
+    const long cols = d->geglu ? 2 * d->N : d->N;
+    const bool vec4 = d->ldc % 4 == 0 && d->N % 4 == 0 && (!d->residual || d->ldr % 4 == 0);
+    const bool eligible = cols % 320 == 0 && nbatch == 1 && !d->geglu && d->c_mode == 0 && vec4;
+    const long tiles = ((d->M + 127) / 128) * ((cols + 319) / 320);
+    const int s = plan_splitk(d, tiles, eligible);
+    return s > 1 ? (int64_t)s * d->M * d->N * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
@@ -642,7 +735,20 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
         (void)hipEventRecord(e0, stream);
     }
     const bool wide = (cols % 320 == 0);
-    if (wide && d->K >= 640 && blocks(256, 320) >= 240) {
+    const int splits = plan_splitk(d, blocks(128, 320), wide && nbatch == 1 && !p.geglu && p.c_mode == 0 && p.vec4);
+    if (splits > 1 && d->workspace != nullptr &&
+        d->workspace_bytes >= (int64_t)splits * d->M * d->N * (int64_t)sizeof(float)) {
+        const long nk = (d->K + BK - 1) / BK;
+        p.splitk = splits;
+        p.nk_per = (int)((nk + splits - 1) / splits);
+        p.ws = (float*)d->workspace;
+        rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);
+        if (rc == VSX_OK) {
+            const long quads = d->M * (d->N / 4);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
+            rc = vsx_check_launch("vsx_gemm_f16 (split-K reduce)");
+        }
+    } else if (wide && d->K >= 640 && blocks(256, 320) >= 240) {
         // 16 waves (1024 threads, 4 per SIMD), 32x160 per wave: 142 FLOP per staged byte — operand delivery into the
         // CU (~7.5 TB/s aggregate measured) is what bounds these kernels, so the tile is as large as LDS allows.
         // Short K loops (K = 320) stay on the 128-row tile: more, smaller workgroups overlap their pro/epilogues.

@@ -51,11 +51,23 @@ class FlopCounter:
         cls.enabled, cls.gemm, cls.attention = enabled, 0.0, 0.0
 
 
+_split_ws = {}      # device -> grow-only fp32 scratch for split-K partial sums (stream-ordered reuse)
+
+
 def gemm(desc):
     if FlopCounter.enabled:
         cols = desc.N * (2 if desc.geglu else 1)
         FlopCounter.gemm += 2.0 * desc.M * cols * desc.K * desc.batch0 * desc.batch1
-    check(_lib.load().vsx_gemm_f16(ctypes.byref(desc), _stream()), 'vsx_gemm_f16')
+    lib = _lib.load()
+    need = lib.vsx_gemm_workspace(ctypes.byref(desc))
+    if need > 0:
+        dev = torch.cuda.current_device()
+        ws = _split_ws.get(dev)
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=f'cuda:{dev}')
+            _split_ws[dev] = ws
+        desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    check(lib.vsx_gemm_f16(ctypes.byref(desc), _stream()), 'vsx_gemm_f16')
 
 
 def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
