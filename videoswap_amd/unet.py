@@ -564,6 +564,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         self.conv_act = nn.SiLU()
         self.conv_out = InflatedConv3d(boc[0], out_channels, kernel_size=3, padding=1)
         self._frame_shard = None      # videoswap_amd.distributed.FrameShard for the long-clip mode
+        self._temb_cache = {}
 
     # ---------------------------------------------------------------------------------------------
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
@@ -588,8 +589,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
             timesteps = torch.tensor([timesteps], dtype=torch.float64 if isinstance(timestep, float) else torch.int64)
         elif timesteps.dim() == 0:
             timesteps = timesteps[None]
-        timesteps = timesteps.expand(B)
-        t_emb = self.time_proj(timesteps).to(device=sample.device, dtype=self.dtype)
+        t_emb = self._timestep_features(timesteps, B, sample.device)
         silu_emb = ops.silu(self.time_embedding(t_emb))        # every consumer applies SiLU first (resnet.py:172)
 
         x = ops.pack_latents(sample.contiguous(), 8)            # [B*F, H, W, 8] (latent channels zero-padded)
@@ -630,6 +630,20 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         if not return_dict:
             return (out,)
         return UNet3DConditionOutput(sample=out)
+
+    def _timestep_features(self, timesteps, B, device):
+        """Sinusoidal features [B, 320] on the device.  The loops visit the same 50 (+50) timesteps for every clip,
+        so the uploaded rows are cached per value: an H2D copy from pageable memory would otherwise drain the stream
+        once per UNet call and keep the host from enqueueing ahead of the GPU."""
+        if timesteps.numel() == 1:
+            key = (float(timesteps.reshape(-1)[0]), str(device), self.dtype)
+            row = self._temb_cache.get(key)
+            if row is None:
+                row = self.time_proj(timesteps.reshape(1)).to(device=device, dtype=self.dtype)
+                if len(self._temb_cache) < 4096:
+                    self._temb_cache[key] = row
+            return row.expand(B, -1).contiguous() if B > 1 else row
+        return self.time_proj(timesteps.expand(B)).to(device=device, dtype=self.dtype)
 
     # ---------------------------------------------------------------------------------------------
     @classmethod
