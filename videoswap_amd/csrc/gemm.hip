@@ -29,6 +29,7 @@
 // transposed store (V^T for the attention kernel).  Accumulators hold C^T (SWAP) so a lane owns one output row and 4
 // consecutive columns per register quad: 8-byte vector loads/stores in the epilogue.
 #include "common.h"
+#include <cstdlib>
 #include <vector>
 #include <stdlib.h>
 
@@ -277,6 +278,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     for (int s = 0; s < PREFETCH; ++s)
         if (s < nloc) issue(kt_begin + s, s);
 
+    // Residual prefetch (8-wave tiles only: the 16-wave tile has no registers to spare): the epilogue's residual
+    // quads are requested now, behind the first operand slabs, so their HBM latency hides under the main loop
+    // instead of stalling every wave at the end of a short K loop.
+    constexpr bool PRE_RES = SWAP && (NW <= 8) && (TM * TN <= 5);
+    h4 rpre[PRE_RES ? TM * TN * 4 : 1];
+    const half_t* Rb0 = p.residual ? p.residual + z0 * p.r_bs0 + z1 * p.r_bs1 : nullptr;
+    const bool pre_res = PRE_RES && Rb0 != nullptr && p.vec4 && !p.geglu && p.splitk <= 1;
+    if constexpr (PRE_RES) {
+        if (pre_res) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = (int)m0 + wr * WM + i * 32 + l31;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = (int)n0 + wc * WN + j * 32 + 8 * g + 4 * hi;
+                        h4 v = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                        if (m < (int)p.M && nb + 3 < (int)p.N)
+                            v = *reinterpret_cast<const h4*>(Rb0 + (unsigned)m * (unsigned)p.ldr + nb);
+                        rpre[(i * TN + j) * 4 + g] = v;
+                    }
+            }
+        }
+    }
+
     for (int kt = 0; kt < nloc; ++kt) {
         // slab kt must have landed; later slabs (at most PREFETCH-1 of them) stay in flight
         const int later = min(nloc - 1 - kt, PREFETCH - 1);
@@ -425,7 +452,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }
                         if (rrow) {
-                            const h4 b = *reinterpret_cast<const h4*>(rrow + nb);
+                            h4 b;
+                            if (PRE_RES && pre_res) b = rpre[PRE_RES ? (i * TN + j) * 4 + g : 0];
+                            else b = *reinterpret_cast<const h4*>(rrow + nb);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }
@@ -748,7 +777,14 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
             rc = vsx_check_launch("vsx_gemm_f16 (split-K reduce)");
         }
-    } else if (wide && d->K >= 640 && blocks(256, 320) >= 240) {
+    } else if (d->K <= 320 && cols % 160 == 0 && !p.geglu && blocks(128, 160) >= 512) {
+        // K = 320 projections are latency/HBM-bound (10 slabs per tile): two 4-wave workgroups per CU overlap one
+        // tile's epilogue with the other's loads (measured 101 vs 111 us with residual, 82 vs 86 us without).
+        rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);
+    } else if (wide && d->K >= 640 && blocks(256, 320) >= 240 &&
+               !(p.residual && p.vec4 && !p.geglu && d->K <= 1280)) {
+        // (residual epilogues with K <= 1280 go to the 8-wave tile below: it has the registers to prefetch the
+        // residual quads behind the first operand slabs; 76 vs 90 us at M=32768, N=K=640)
         // 16 waves (1024 threads, 4 per SIMD), 32x160 per wave: 142 FLOP per staged byte — operand delivery into the
         // CU (~7.5 TB/s aggregate measured) is what bounds these kernels, so the tile is as large as LDS allows.
         // Short K loops (K = 320) stay on the 128-row tile: more, smaller workgroups overlap their pro/epilogues.
