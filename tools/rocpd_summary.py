@@ -19,6 +19,25 @@ def main(path):
     for name, n, tot, avg, mn, mx in rows:
         short = name if len(name) < 110 else name[:107] + '...'
         print(f'{n:7d} {tot / 1e6:10.3f} {avg / 1e3:9.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100 * tot / total:5.1f}%  {short}')
+    # idle time between consecutive dispatches (gaps above 1 ms are phase boundaries / host work, listed apart)
+    ev = c.execute('select start, end from kernels order by start').fetchall()
+    small = big = 0
+    nsmall = nbig = 0
+    hi = ev[0][1] if ev else 0
+    for st, en in ev[1:]:
+        if st > hi:
+            g = st - hi
+            if g < 1_000_000:
+                small += g
+                nsmall += 1
+            else:
+                big += g
+                nbig += 1
+        hi = max(hi, en)
+    if ev:
+        span = hi - ev[0][0]
+        print(f'# span {span / 1e6:.3f} ms; idle between dispatches: {small / 1e6:.3f} ms in {nsmall} gaps < 1 ms '
+              f'({100 * small / span:.1f}% of span), {big / 1e6:.3f} ms in {nbig} gaps >= 1 ms')
 
 
 if __name__ == '__main__':

@@ -190,10 +190,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         t_c = t_second ? rem - p.C1 : rem;
     }
 
-    auto issue = [&](int kt, int stage) {
+    // A slab is staged in two steps so that its 1-KiB DMA pieces can be issued one at a time BETWEEN the MFMAs of the
+    // main loop: issue_prep() advances the (wave-uniform) tap state and fixes the slab's offsets, issue_piece(q)
+    // issues piece q (A pieces first, then this wave's B pieces).  Issuing all pieces of all 8 waves in one burst
+    // right after the barrier kept the CU's address path busy for ~500 cycles per slab with the matrix pipes idle.
+    unsigned char* i_sb = smem;
+    bool i_tail = false, i_second = false;
+    int i_soffA = 0, i_soffB = 0;
+    auto issue_prep = [&](int kt, int stage) {
         unsigned char* sb = smem + stage * STAGE;
         const bool last_tail = (kt == nk - 1) && ktail_lane;
-        int soffA = kt * (BK * 2);
+        int soffA = kt * (BK * 2), soffB = kt * (BK * 2);
         bool second = false;
         if (p.a_mode == 1) {
             if (fast_tap) {
@@ -237,24 +244,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                 soffA = 0;
             }
         }
-#pragma unroll
-        for (int i = 0; i < GA; ++i) {
-            const int v = last_tail ? OOB_OFF : va[i];
-            lptr_t dst = (lptr_t)(sb + (wave * GA + i) * 1024);
-            if (second)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, dst, 16, v, soffA, 0, 0);
+        i_sb = sb; i_tail = last_tail; i_second = second; i_soffA = soffA; i_soffB = soffB;
+    };
+    constexpr int NPIECE = GA + GB_HI;
+    bool i_on = true;                               // false: nothing left to stage (the tail of the K loop)
+    auto issue_piece = [&](const int q) {           // q is a compile-time constant at every call site
+        if (!i_on) return;
+        if (q < GA) {
+            const int v = i_tail ? OOB_OFF : va[q < GA ? q : 0];
+            lptr_t dst = (lptr_t)(i_sb + (wave * GA + q) * 1024);
+            if (i_second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, dst, 16, v, i_soffA, 0, 0);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, soffA, 0, 0);
-        }
-        const int soffB = kt * (BK * 2);
-#pragma unroll
-        for (int j = 0; j < GB_HI; ++j) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, i_soffA, 0, 0);
+        } else {
+            const int j = q - GA;
             if (j < gbw) {   // wave-uniform
-                const int v = last_tail ? OOB_OFF : vb[j];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(sb + BM * 64 + (b_blk0 + j) * 1024), 16, v,
-                                                         soffB, 0, 0);
+                const int v = i_tail ? OOB_OFF : vb[j < GB_HI ? j : 0];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(i_sb + BM * 64 + (b_blk0 + j) * 1024), 16, v,
+                                                         i_soffB, 0, 0);
             }
         }
+    };
+    auto issue = [&](int kt, int stage) {
+        issue_prep(kt, stage);
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) issue_piece(q);
     };
 
     constexpr int NACC = SWAP ? TN : TM, MACC = SWAP ? TM : TN;
@@ -304,8 +319,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         }
     }
 
-    for (int kt = 0; kt < nloc; ++kt) {
-        // slab kt must have landed; later slabs (at most PREFETCH-1 of them) stay in flight
+    // slab kt must have landed; later slabs (at most PREFETCH-1 of them) stay in flight
+    auto wait_slab = [&](const int kt) {
         const int later = min(nloc - 1 - kt, PREFETCH - 1);
         if (wave < N_HI) {
             constexpr int G = GA + GB_HI;
@@ -318,27 +333,87 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             else if (PREFETCH >= 2 && later == 1) wait_vmcnt<G>();
             else wait_vmcnt<0>();
         }
-        __builtin_amdgcn_s_barrier();   // everybody's part of slab kt is in LDS; slot (kt-1)%NSTAGE is free
-        if (kt + PREFETCH < nloc) issue(kt_begin + kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
+    };
+    auto ldfrag = [&](const unsigned char* sb, const int off, h8 (&af)[TM], h8 (&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8*>(sb + a_row + i * 2048 + off);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8*>(sb + b_row + j * 2048 + off);
+    };
+    auto mma = [&](const h8 (&af)[TM], const h8 (&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (SWAP)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[j][i], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+    };
 
-        const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
+    // the MFMAs of one k-step with one DMA piece of the slab being staged after each of them
+    auto mma_issue = [&](const h8 (&af)[TM], const h8 (&bf)[TN]) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int off = ks ? off1 : off0;
-            h8 af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8*>(sb + a_row + i * 2048 + off);
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (SWAP)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[j][i], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if (i * TN + j < NPIECE) issue_piece(i * TN + j);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8*>(sb + b_row + j * 2048 + off);
+        for (int q = TM * TN; q < NPIECE; ++q) issue_piece(q);
+    };
+
+    // Register-double-buffered fragments (<= 8 waves: the 16-wave tile has 128 registers per lane and relies on its four
+    // waves per SIMD instead).  The fragments of k-step s+1 are requested from LDS BEFORE the MFMAs of k-step s are
+    // issued, so the LDS round trip always sits behind 5-10 MFMAs of the same wave; the first version read each
+    // fragment immediately before the MFMA that consumed it (s_waitcnt lgkmcnt(0) in front of every MFMA) and a lone
+    // workgroup ran at 38 % of the MFMA rate (tools/tile_probe.py).
+    constexpr bool PIPE = (NW <= 8);
+    if constexpr (PIPE) {
+        h8 af0[TM], bf0[TN], af1[TM], bf1[TN];
+        wait_slab(0);
+        __builtin_amdgcn_s_barrier();
+        if (PREFETCH < nloc) issue(kt_begin + PREFETCH, PREFETCH & (NSTAGE - 1));
+        ldfrag(smem, off0, af0, bf0);
+        for (int kt = 0; kt + 1 < nloc; ++kt) {
+            const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
+            ldfrag(sb, off1, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_slab(kt + 1);
+            // every fragment read of slab kt has returned before its ring slot is handed back to the DMA engine
+            __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            i_on = kt + 1 + PREFETCH < nloc;
+            if (i_on) issue_prep(kt_begin + kt + 1 + PREFETCH, (kt + 1 + PREFETCH) & (NSTAGE - 1));
+            ldfrag(smem + ((kt + 1) & (NSTAGE - 1)) * STAGE, off0, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_issue(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (nloc > 0) {                                  // last slab: nothing left to stage
+            ldfrag(smem + ((nloc - 1) & (NSTAGE - 1)) * STAGE, off1, af1, bf1);
+            mma(af0, bf0);
+            mma(af1, bf1);
+        }
+    } else {
+        for (int kt = 0; kt < nloc; ++kt) {
+            wait_slab(kt);
+            __builtin_amdgcn_s_barrier();   // everybody's part of slab kt is in LDS; slot (kt-1)%NSTAGE is free
+            if (kt + PREFETCH < nloc) issue(kt_begin + kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
+            const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (SWAP)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[j][i], 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-                }
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 af[TM], bf[TN];
+                ldfrag(sb, ks ? off1 : off0, af, bf);
+                mma(af, bf);
+            }
         }
     }
 
@@ -635,6 +710,16 @@ extern "C" int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* t
     return VSX_OK;
 }
 
+// Diagnostics only (tools/tile_probe.py): VSX_TUNE_TILE=1|2|3 forces the 128x320 / 128x160 / 256x320 tile, no split-K.
+static long force_tile() {
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("VSX_TUNE_TILE");
+        v = e ? atol(e) : 0;
+    }
+    return v;
+}
+
 extern "C" int64_t vsx_gemm_workspace(const vsx_gemm_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
     const long nbatch = d->batch0 * d->batch1;
@@ -765,7 +850,11 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     }
     const bool wide = (cols % 320 == 0);
     const int splits = plan_splitk(d, blocks(128, 320), wide && nbatch == 1 && !p.geglu && p.c_mode == 0 && p.vec4);
-    if (splits > 1 && d->workspace != nullptr &&
+    if (force_tile() && wide) {
+        if (force_tile() == 1) rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);
+        else if (force_tile() == 2) rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);
+        else rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
+    } else if (splits > 1 && d->workspace != nullptr &&
         d->workspace_bytes >= (int64_t)splits * d->M * d->N * (int64_t)sizeof(float)) {
         const long nk = (d->K + BK - 1) / BK;
         p.splitk = splits;

@@ -78,33 +78,38 @@ __global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t*
     }
 }
 
-// grid (nimg), block 256: mean / rstd of every (image, group) from the per-chunk partial sums — 256 threads =
-// (256/groups) chunk subsets x groups, then a fixed-order combine (deterministic; identical on every rank)
+// grid (groups, nimg), block 256: mean / rstd of one (image, group) from its per-chunk partial sums.  The 5-D
+// GroupNorm has ~1000 chunks per image: every thread issues its (independent) loads back to back and the combine is
+// a fixed-shape tree, so the kernel is a few microseconds and the result is deterministic (identical on every rank).
+// (The first version walked the chunks serially in 8 threads per group: 13 us per call, 81 calls per forward.)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int groups,
                                                           float inv_count, float eps, float* __restrict__ stats) {
-    __shared__ float s_part[256][2];
+    __shared__ float s_a[256];
+    __shared__ float s_b[256];
     const int tid = threadIdx.x;
-    const long img = blockIdx.x;
-    const int nsub = 256 / groups;                  // groups <= 64 -> nsub >= 4
-    const int g = tid % groups, sub = tid / groups;
+    const int g = blockIdx.x;
+    const long img = blockIdx.y;
+    const float2* pp = reinterpret_cast<const float2*>(partial) + img * nchunks * groups + g;
     float a = 0.f, b = 0.f;
-    if (sub < nsub) {
-        const float* pp = partial + (img * nchunks * groups + g) * 2;
-        for (int ch = sub; ch < nchunks; ch += nsub) {
-            a += pp[(long)ch * groups * 2];
-            b += pp[(long)ch * groups * 2 + 1];
-        }
+#pragma unroll 8
+    for (int ch = tid; ch < nchunks; ch += 256) {
+        const float2 v = pp[(long)ch * groups];
+        a += v.x;
+        b += v.y;
     }
-    s_part[tid][0] = a;
-    s_part[tid][1] = b;
+    s_a[tid] = a;
+    s_b[tid] = b;
     __syncthreads();
-    if (tid < groups) {
-        float sa = 0.f, sb = 0.f;
-        for (int k = 0; k < nsub; ++k) { sa += s_part[k * groups + tid][0]; sb += s_part[k * groups + tid][1]; }
-        const float mean = sa * inv_count;
-        const float var = fmaxf(sb * inv_count - mean * mean, 0.f);
-        stats[(img * groups + tid) * 2] = mean;
-        stats[(img * groups + tid) * 2 + 1] = rsqrtf(var + eps);
+#pragma unroll
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) { s_a[tid] += s_a[tid + w]; s_b[tid] += s_b[tid + w]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float mean = s_a[0] * inv_count;
+        const float var = fmaxf(s_b[0] * inv_count - mean * mean, 0.f);
+        stats[(img * groups + g) * 2] = mean;
+        stats[(img * groups + g) * 2 + 1] = rsqrtf(var + eps);
     }
 }
 
@@ -288,7 +293,7 @@ extern "C" int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg,
                 "groupnorm_apply: gamma/beta/y must be 16-byte aligned");
     const int64_t C = C1 + C2;
     const float inv_count = 1.0f / ((float)count_rows * (float)(C / groups));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nimg), dim3(256), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)groups, (unsigned)nimg), dim3(256), 0, (hipStream_t)stream, partial,
                        (int)nchunks, (int)groups, inv_count, eps, stats);
     const int rpb = gn_apply_rows(rows, nimg);
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nimg);
