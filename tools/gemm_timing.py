@@ -1,0 +1,75 @@
+"""Where does a GEMM workgroup spend its main loop?  Builds a -DVSX_GEMM_TIMING copy of the library (per-wave cycle
+totals of: MFMA+fragment segment / DMA-landing wait / barrier wait / DMA issue), runs one forced tile shape and prints
+the per-slab averages.
+
+    python tools/gemm_timing.py build                     # here (cross-compile)
+    VSX_TUNE_TILE=1 python tools/gemm_timing.py run M N K   # on the GPU box
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, 'videoswap_amd', 'lib', 'libvsx_timing.so')
+
+
+def build():
+    from videoswap_amd import build as b
+    objs = []
+    for src in b.SOURCES:
+        obj = os.path.join(b.OBJDIR, 'timing_' + src + '.o')
+        subprocess.check_call([b.HIPCC] + b.FLAGS + ['-DVSX_GEMM_TIMING', '-c', os.path.join(b.CSRC, src), '-o', obj])
+        objs.append(obj)
+    subprocess.check_call([b.HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    print('built', LIB)
+
+
+def run(M, N, K, iters=5):
+    import torch
+    from videoswap_amd import _lib
+    _lib.LIB_PATH = LIB
+    lib = _lib.load()
+    tile = int(os.environ.get('VSX_TUNE_TILE', '1'))
+    BM, BN, NW = {1: (128, 320, 8), 2: (128, 160, 4), 3: (256, 320, 16), 4: (256, 320, 8)}[tile]
+    x = torch.randn(M, K, device='cuda', dtype=torch.float16)
+    w = torch.randn(N, K, device='cuda', dtype=torch.float16) * 0.02
+    out = torch.empty(M, N, device='cuda', dtype=torch.float16)
+    nblk = ((M + BM - 1) // BM) * ((N + BN - 1) // BN)
+    ws = torch.zeros(nblk * NW * 4, dtype=torch.int64, device='cuda')
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.batch0 = d.batch1 = 1
+    d.A = x.data_ptr(); d.lda = K
+    d.B = w.data_ptr(); d.ldb = K
+    d.C = out.data_ptr(); d.ldc = N
+    d.alpha = 1.0
+    d.workspace = ws.data_ptr(); d.workspace_bytes = ws.numel() * 8
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(iters):
+        _lib.check(lib.vsx_gemm_f16(ctypes.byref(d), ctypes.c_void_p(s)), 'gemm')
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    _lib.check(lib.vsx_gemm_f16(ctypes.byref(d), ctypes.c_void_p(s)), 'gemm')
+    b.record(); b.synchronize()
+    us = a.elapsed_time(b) * 1e3
+    t = ws.view(nblk, NW, 4).double()
+    nslab = (K + 63) // 64
+    per = t.mean(dim=(0, 1)) / max(nslab - 1, 1)
+    tot = per.sum().item()
+    names = ['MFMA + fragment reads', 'wait: DMA landed', 'wait: barrier', 'DMA issue (+ frag/MFMA tail)']
+    print(f'tile {BM}x{BN} ({NW} waves)  M={M} N={N} K={K}: {nblk} workgroups, {us:.1f} us, '
+          f'{2.0 * M * N * K / us / 1e6:.0f} TFLOP/s; per-slab cycles (mean over waves): total {tot:.0f}')
+    for n, v in zip(names, per.tolist()):
+        print(f'    {n:32s} {v:8.0f} cyc  {100 * v / tot:5.1f}%')
+    wv = t.mean(dim=0) / max(nslab - 1, 1)
+    print('    per-wave totals:', [f'{v:.0f}' for v in wv.sum(dim=1).tolist()])
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'build':
+        build()
+    else:
+        run(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))

@@ -35,7 +35,7 @@
 
 namespace {
 
-constexpr int BK = 32;          // K slab (halfs); LDS rows are 64 B = 4 16-byte slots
+constexpr int BK = 64;          // K slab (halfs); LDS rows are 128 B = 8 16-byte slots = one full L2 line per row
 // LDS ring depth NSTAGE is a template parameter: 4 slots (3 slabs in flight) for long K loops; 2 slots for short ones
 // (K <= 640), where halving the LDS footprint lets two workgroups share a CU and overlap one's prologue / epilogue
 // with the other's main loop — the dominant cost when the loop is only 10-20 slabs long
@@ -64,6 +64,14 @@ struct GemmParams {
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// -DVSX_GEMM_TIMING (tools/gemm_timing.py builds its own copy of the library): per-wave cycle totals of the main-loop
+// segments, written to the workspace as long[block][wave][4].  Never defined in the product build.
+#ifdef VSX_GEMM_TIMING
+#define TSTAMP(i) do { const long t_now = (long)clock64(); t_seg[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define TSTAMP(i) do { } while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -79,12 +87,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int A_BLKS = BM / 16, B_BLKS = BN / 16;           // 16-row LDS-DMA blocks per operand
+    constexpr int A_BLKS = BM / 8, B_BLKS = BN / 8;             // 8-row (8 x 128 B = 1 KiB) LDS-DMA pieces per operand
     static_assert(A_BLKS % NW == 0, "A blocks must split evenly over the waves");
     constexpr int GA = A_BLKS / NW;
     constexpr int GB_LO = B_BLKS / NW, GB_HI = (B_BLKS + NW - 1) / NW;
     constexpr int N_HI = B_BLKS - GB_LO * NW;                   // waves [0, N_HI) issue GB_HI B blocks, the rest GB_LO
-    constexpr int STAGE = (BM + BN) * 64;                       // bytes per ring slot
+    constexpr int STAGE = (BM + BN) * 128;                      // bytes per ring slot
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -115,11 +123,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     const half_t* Ab = p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
     const half_t* Bb = p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
 
-    // ---- LDS-DMA coordinates: lane -> (row lrow of a 16-row block, physical 16-byte slot pslot) ----
+    // ---- LDS-DMA coordinates: lane -> (row lrow of an 8-row piece, physical 16-byte slot pslot).  The LDS image is
+    // lane-linear, so the XOR swizzle (slot ^= (tile_row >> 1) & 7) is applied to the SOURCE column: a lane's k offset
+    // inside a slab depends on its row and on the parity of the piece (tile_row = piece * 8 + lrow) ----
     constexpr int OOB_OFF = (int)0x80000000;
-    const int lrow = lane >> 2;
-    const int pslot = lane & 3;
-    const int kofs = (pslot ^ ((lrow >> 2) & 3)) * 8;     // this lane's k offset inside every slab
+    const int lrow = lane >> 3;
+    const int pslot = lane & 7;
+    const int kofs_e = (pslot ^ (lrow >> 1)) * 8;           // even pieces
+    const int kofs_o = (pslot ^ (4 | (lrow >> 1))) * 8;     // odd pieces
 
     const __amdgpu_buffer_rsrc_t rsrcA =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Ab), 0, (int)p.a_bytes, 0x00020000);
@@ -129,17 +140,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Bb), 0, (int)p.b_bytes, 0x00020000);
 
     bool a_ok[GA];
-    int a_h0[GA], a_w0[GA], a_ibase[GA];
+    int a_h0[GA], a_w0[GA], a_ibase[GA], a_kofs[GA];
     int va[GA];                                   // current voffset of each A row (plain: fixed; conv: per tap)
     const int Hs = p.ups ? (p.H >> 1) : p.H;
     const int Ws = p.ups ? (p.W >> 1) : p.W;
     const int pad = p.ks >> 1;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-        const long m = m0 + (wave * GA + i) * 16 + lrow;
+        const long m = m0 + (wave * GA + i) * 8 + lrow;
         a_ok[i] = m < p.M;
         a_h0[i] = 0; a_w0[i] = 0; a_ibase[i] = 0;
-        va[i] = a_ok[i] ? (int)((m * p.lda + kofs) * 2) : OOB_OFF;
+        a_kofs[i] = ((wave * GA + i) & 1) ? kofs_o : kofs_e;
+        va[i] = a_ok[i] ? (int)((m * p.lda + a_kofs[i]) * 2) : OOB_OFF;
         if (p.a_mode == 1) {
             const long hw = (long)p.Ho * p.Wo;
             const long mm = a_ok[i] ? m : 0;
@@ -154,10 +166,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // this wave's B blocks: [b_blk0, b_blk0 + gbw)
     const int gbw = wave < N_HI ? GB_HI : GB_LO;
     const int b_blk0 = wave < N_HI ? wave * GB_HI : N_HI * GB_HI + (wave - N_HI) * GB_LO;
-    int vb[GB_HI];
+    int vb[GB_HI], b_kofs[GB_HI];
 #pragma unroll
     for (int j = 0; j < GB_HI; ++j) {
-        const int jr = (b_blk0 + j) * 16 + lrow;      // row inside the B tile
+        const int jr = (b_blk0 + j) * 8 + lrow;       // row inside the B tile
+        b_kofs[j] = ((b_blk0 + j) & 1) ? kofs_o : kofs_e;
         long n;
         bool ok;
         if (p.geglu) {   // inside every 32-row MFMA tile: rows 0-15 = h columns, rows 16-31 = the matching g columns
@@ -168,12 +181,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             n = n0 + jr;
             ok = n < p.N;
         }
-        vb[j] = (ok && j < gbw) ? (int)((n * p.ldb + kofs) * 2) : OOB_OFF;
+        vb[j] = (ok && j < gbw) ? (int)((n * p.ldb + b_kofs[j]) * 2) : OOB_OFF;
     }
 
     const int Ctot = p.C1 + p.C2;
     const int nk = (int)((p.K + BK - 1) / BK);
-    const bool ktail_lane = (long)(nk - 1) * BK + kofs >= p.K;      // only possible when K % 32 != 0
+    const int ktail_from = (int)(p.K - (long)(nk - 1) * BK);         // last slab: k offsets >= this are beyond K
     // conv fast path: a K slab never straddles a filter tap or the two concatenated sources, so (kh, kw, source,
     // channel base) are wave-uniform running counters and the row offsets change only when the tap does
     const bool fast_tap = p.a_mode == 1 && (Ctot % BK == 0) && (p.C1 % BK == 0);
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     int i_soffA = 0, i_soffB = 0;
     auto issue_prep = [&](int kt, int stage) {
         unsigned char* sb = smem + stage * STAGE;
-        const bool last_tail = (kt == nk - 1) && ktail_lane;
+        const bool last_tail = (kt == nk - 1) && ktail_from < BK;
         int soffA = kt * (BK * 2), soffB = kt * (BK * 2);
         bool second = false;
         if (p.a_mode == 1) {
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         const int hh = a_h0[i] + t_kh, ww = a_w0[i] + t_kw;
                         const bool ok = a_ok[i] && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W;
                         const int hsrc = p.ups ? (hh >> 1) : hh, wsrc = p.ups ? (ww >> 1) : ww;
-                        va[i] = ok ? (((a_ibase[i] + hsrc) * Ws + wsrc) * cs + kofs) * 2 : OOB_OFF;
+                        va[i] = ok ? (((a_ibase[i] + hsrc) * Ws + wsrc) * cs + a_kofs[i]) * 2 : OOB_OFF;
                     }
                     t_dirty = false;
                 }
@@ -229,13 +242,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                     }
                 }
             } else {           // generic path (conv_in: 8 padded input channels): per-lane tap decode, single source
-                const long k = (long)kt * BK + kofs;
-                const int kk = k < p.K ? (int)k : 0;
-                const int tap = kk / Ctot;
-                const int ci = kk - tap * Ctot;
-                const int kh = tap / p.ks, kw = tap - kh * p.ks;
 #pragma unroll
                 for (int i = 0; i < GA; ++i) {
+                    const long k = (long)kt * BK + a_kofs[i];
+                    const int kk = k < p.K ? (int)k : 0;
+                    const int tap = kk / Ctot;
+                    const int ci = kk - tap * Ctot;
+                    const int kh = tap / p.ks, kw = tap - kh * p.ks;
                     const int hh = a_h0[i] + kh, ww = a_w0[i] + kw;
                     const bool ok = a_ok[i] && k < p.K && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W;
                     const int hsrc = p.ups ? (hh >> 1) : hh, wsrc = p.ups ? (ww >> 1) : ww;
@@ -248,10 +261,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     };
     constexpr int NPIECE = GA + GB_HI;
     bool i_on = true;                               // false: nothing left to stage (the tail of the K loop)
+    bool i_gate = true;                             // this call site's share of the staggered issue (see mma_issue)
     auto issue_piece = [&](const int q) {           // q is a compile-time constant at every call site
-        if (!i_on) return;
+        if (!(i_on && i_gate)) return;
         if (q < GA) {
-            const int v = i_tail ? OOB_OFF : va[q < GA ? q : 0];
+            const int qi = q < GA ? q : 0;
+            const int v = (i_tail && a_kofs[qi] >= ktail_from) ? OOB_OFF : va[qi];
             lptr_t dst = (lptr_t)(i_sb + (wave * GA + q) * 1024);
             if (i_second)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, dst, 16, v, i_soffA, 0, 0);
@@ -260,14 +275,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         } else {
             const int j = q - GA;
             if (j < gbw) {   // wave-uniform
-                const int v = i_tail ? OOB_OFF : vb[j < GB_HI ? j : 0];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(i_sb + BM * 64 + (b_blk0 + j) * 1024), 16, v,
+                const int jj = j < GB_HI ? j : 0;
+                const int v = (i_tail && b_kofs[jj] >= ktail_from) ? OOB_OFF : vb[jj];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(i_sb + BM * 128 + (b_blk0 + j) * 1024), 16, v,
                                                          i_soffB, 0, 0);
             }
         }
     };
     auto issue = [&](int kt, int stage) {
         issue_prep(kt, stage);
+        i_on = true;
+        i_gate = true;
 #pragma unroll
         for (int q = 0; q < NPIECE; ++q) issue_piece(q);
     };
@@ -281,12 +299,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // fragment read offsets: row (.. + l31) * 64 B, logical slot ks*2 + hi, swizzled by (l31 >> 2) & 3
-    const int swz = (l31 >> 2) & 3;
-    const int a_row = (wr * WM + l31) * 64;
-    const int b_row = BM * 64 + (wc * WN + l31) * 64;
-    const int off0 = ((0 * 2 + hi) ^ swz) * 16;
-    const int off1 = ((1 * 2 + hi) ^ swz) * 16;
+    // fragment read offsets: row (.. + l31) * 128 B, logical slot s*2 + hi of k-step s, swizzled by (row >> 1) & 7.
+    // A ds_read_b128 is served in 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, same + 32): their 8 even and
+    // 8 odd rows take 8 distinct (row >> 1) & 7 values, i.e. 16 distinct 16-B slots of the 256-B bank row.
+    const int swz = (l31 >> 1) & 7;
+    const int a_row = (wr * WM + l31) * 128;
+    const int b_row = BM * 128 + (wc * WN + l31) * 128;
+    int offs[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) offs[ks] = ((ks * 2 + hi) ^ swz) * 16;
 
     const int nloc = kt_end - kt_begin;
 #pragma unroll
@@ -336,9 +357,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     };
     auto ldfrag = [&](const unsigned char* sb, const int off, h8 (&af)[TM], h8 (&bf)[TN]) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8*>(sb + a_row + i * 2048 + off);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const h8*>(sb + a_row + i * 4096 + off);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8*>(sb + b_row + j * 2048 + off);
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const h8*>(sb + b_row + j * 4096 + off);
     };
     auto mma = [&](const h8 (&af)[TM], const h8 (&bf)[TN]) {
 #pragma unroll
@@ -352,8 +373,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             }
     };
 
-    // the MFMAs of one k-step with one DMA piece of the slab being staged after each of them
-    auto mma_issue = [&](const h8 (&af)[TM], const h8 (&bf)[TN]) {
+    // The MFMAs of one k-step with one DMA piece of the slab being staged after each of them.  The CU's address/data
+    // path moves 64 B/clk: a 56-KiB slab keeps it busy ~900 cycles of the ~1300 the slab's MFMAs need, and a wave whose
+    // DMA instruction meets a full queue stalls (tools/gemm_timing.py: 560 of 2170 cycles per slab), during which only
+    // the OTHER wave of its SIMD can feed the matrix pipe.  So the two waves of a SIMD (w and w + NW/2) take turns: the
+    // first half of the workgroup stages in the last k-step of a slab, the second half in the first k-step of the
+    // next one.  (Spreading every wave's pieces over three k-steps was measured too: better for a lone workgroup,
+    // worse under load — the pieces land later and the K = 320 loops are only five slabs long.)
+    auto mma_issue = [&](const h8 (&af)[TM], const h8 (&bf)[TN], const bool gate) {
+        i_gate = gate;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -373,50 +401,88 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // issued, so the LDS round trip always sits behind 5-10 MFMAs of the same wave; the first version read each
     // fragment immediately before the MFMA that consumed it (s_waitcnt lgkmcnt(0) in front of every MFMA) and a lone
     // workgroup ran at 38 % of the MFMA rate (tools/tile_probe.py).
-    constexpr bool PIPE = (NW <= 8);
+#ifdef VSX_GEMM_TIMING
+    long t_seg[4] = {0, 0, 0, 0}, t_last = 0;
+#endif
+    constexpr bool PIPE = (NW <= 8) && (TM * TN < 10);
     if constexpr (PIPE) {
         h8 af0[TM], bf0[TN], af1[TM], bf1[TN];
         wait_slab(0);
         __builtin_amdgcn_s_barrier();
         if (PREFETCH < nloc) issue(kt_begin + PREFETCH, PREFETCH & (NSTAGE - 1));
-        ldfrag(smem, off0, af0, bf0);
+        ldfrag(smem, offs[0], af0, bf0);
+        const bool late = NW >= 8 && wave >= NW / 2;      // second wave of each SIMD: stages one k-step later
+        i_on = false;
+#ifdef VSX_GEMM_TIMING
+        t_last = (long)clock64();
+#endif
         for (int kt = 0; kt + 1 < nloc; ++kt) {
             const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
-            ldfrag(sb, off1, af1, bf1);
+            ldfrag(sb, offs[1], af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_issue(af0, bf0, late);                    // (late waves: the slab prepared in the previous iteration)
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(sb, offs[2], af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldfrag(sb, offs[3], af1, bf1);
             __builtin_amdgcn_sched_barrier(0);
             mma(af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
+            TSTAMP(0);
             wait_slab(kt + 1);
             // every fragment read of slab kt has returned before its ring slot is handed back to the DMA engine
             __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+            TSTAMP(1);
             __builtin_amdgcn_s_barrier();
+            TSTAMP(2);
             i_on = kt + 1 + PREFETCH < nloc;
             if (i_on) issue_prep(kt_begin + kt + 1 + PREFETCH, (kt + 1 + PREFETCH) & (NSTAGE - 1));
-            ldfrag(smem + ((kt + 1) & (NSTAGE - 1)) * STAGE, off0, af0, bf0);
+            ldfrag(smem + ((kt + 1) & (NSTAGE - 1)) * STAGE, offs[0], af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
-            mma_issue(af1, bf1);
+            mma_issue(af1, bf1, !late);
             __builtin_amdgcn_sched_barrier(0);
+            TSTAMP(3);
         }
         if (nloc > 0) {                                  // last slab: nothing left to stage
-            ldfrag(smem + ((nloc - 1) & (NSTAGE - 1)) * STAGE, off1, af1, bf1);
+            const unsigned char* sb = smem + ((nloc - 1) & (NSTAGE - 1)) * STAGE;
+            ldfrag(sb, offs[1], af1, bf1);
+            mma(af0, bf0);
+            ldfrag(sb, offs[2], af0, bf0);
+            mma(af1, bf1);
+            ldfrag(sb, offs[3], af1, bf1);
             mma(af0, bf0);
             mma(af1, bf1);
         }
     } else {
+#ifdef VSX_GEMM_TIMING
+        t_last = (long)clock64();
+#endif
         for (int kt = 0; kt < nloc; ++kt) {
             wait_slab(kt);
+            TSTAMP(1);
             __builtin_amdgcn_s_barrier();   // everybody's part of slab kt is in LDS; slot (kt-1)%NSTAGE is free
+            TSTAMP(2);
             if (kt + PREFETCH < nloc) issue(kt_begin + kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
+            TSTAMP(3);
             const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < 4; ++ks) {
                 h8 af[TM], bf[TN];
-                ldfrag(sb, ks ? off1 : off0, af, bf);
+                ldfrag(sb, offs[ks], af, bf);
                 mma(af, bf);
             }
+            TSTAMP(0);
         }
     }
 
+#ifdef VSX_GEMM_TIMING
+    if (lane == 0 && p.ws) {
+        long* o = reinterpret_cast<long*>(p.ws) + ((long)blockIdx.x * NW + wave) * 4;
+        for (int k = 0; k < 4; ++k) o[k] = t_seg[k];
+    }
+#endif
     // ---------------- epilogue (32-bit element offsets: the host guarantees M*ldc, M*ldr < 2^31) ----------------
     half_t* Cb = p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
     const half_t* Rb = p.residual ? p.residual + z0 * p.r_bs0 + z1 * p.r_bs1 : nullptr;
@@ -638,13 +704,13 @@ inline int plan_splitk(const vsx_gemm_desc* d, long tiles, bool eligible) {
     const long nk = (d->K + BK - 1) / BK;
     int s = (int)((256 + tiles - 1) / tiles);
     if (s > 8) s = 8;
-    while (s > 1 && nk / s < 24) --s;     // keep >= 24 slabs per slice
+    while (s > 1 && nk / s < 12) --s;     // keep >= 12 slabs (768 k) per slice
     return s;
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP, int NSTAGE>
 int launch(const GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
-    constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * 64;
+    constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS ring exceeds 160 KiB");
     static bool attr_set = false;
     if (!attr_set) {
@@ -663,10 +729,10 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_tile(GemmParams& p, long M, long cols, long nbatch, hipStream_t stream) {
     p.tiles_n = (int)((cols + BN - 1) / BN);
     const long tiles_m = (M + BM - 1) / BM;
-    if (p.c_mode == 1) return launch<BM, BN, WAVES_M, WAVES_N, false, 4>(p, tiles_m, nbatch, stream);
-    // measured: the 2-slot ring pays for the epilogue-heavy GEGLU (+15-20 %), not for the memory-bound plain GEMMs
-    if (p.geglu && p.K <= 640) return launch<BM, BN, WAVES_M, WAVES_N, true, 2>(p, tiles_m, nbatch, stream);
-    return launch<BM, BN, WAVES_M, WAVES_N, true, 4>(p, tiles_m, nbatch, stream);
+    // ring depth: two 128-byte-row slabs for the big tiles (57-74 KiB per slab), four for the small ones
+    constexpr int NST = ((BM + BN) * 128 * 4 <= 96 * 1024) ? 4 : 2;
+    if (p.c_mode == 1) return launch<BM, BN, WAVES_M, WAVES_N, false, NST>(p, tiles_m, nbatch, stream);
+    return launch<BM, BN, WAVES_M, WAVES_N, true, NST>(p, tiles_m, nbatch, stream);
 }
 
 // ---- instrumentation (bench.py roofline): hipEvent pairs around sampled launches ----
@@ -794,8 +860,8 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
         VSX_REQUIRE((d->C2 == 0) == (d->A2 == nullptr), VSX_E_BADSHAPE, "gemm: A2/C2 mismatch");
         VSX_REQUIRE(d->A2 == nullptr || vsx_aligned16(d->A2), VSX_E_BADSHAPE, "gemm: A2 must be 16-byte aligned");
         VSX_REQUIRE(d->K == d->ks * d->ks * (d->C1 + d->C2), VSX_E_BADSHAPE, "gemm: conv K mismatch");
-        VSX_REQUIRE(d->C2 == 0 || (d->C1 % 32 == 0 && d->C2 % 32 == 0), VSX_E_UNSUPPORTED,
-                    "gemm: a two-source conv needs both channel counts to be multiples of 32");
+        VSX_REQUIRE(d->C2 == 0 || (d->C1 % 64 == 0 && d->C2 % 64 == 0), VSX_E_UNSUPPORTED,
+                    "gemm: a two-source conv needs both channel counts to be multiples of 64 (one K slab)");
         VSX_REQUIRE(d->H > 0 && d->W > 0, VSX_E_BADSHAPE, "gemm: conv H/W");
         VSX_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), VSX_E_BADSHAPE, "gemm: upsample needs even H/W");
         p.H = (int)d->H; p.W = (int)d->W; p.C1 = (int)d->C1; p.C2 = (int)d->C2;
@@ -851,9 +917,11 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     const bool wide = (cols % 320 == 0);
     const int splits = plan_splitk(d, blocks(128, 320), wide && nbatch == 1 && !p.geglu && p.c_mode == 0 && p.vec4);
     if (force_tile() && wide) {
+        p.ws = (float*)d->workspace;
         if (force_tile() == 1) rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);
         else if (force_tile() == 2) rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);
-        else rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
+        else if (force_tile() == 3) rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
+        else rc = launch_tile<256, 320, 4, 2>(p, d->M, cols, nbatch, stream);
     } else if (splits > 1 && d->workspace != nullptr &&
         d->workspace_bytes >= (int64_t)splits * d->M * d->N * (int64_t)sizeof(float)) {
         const long nk = (d->K + BK - 1) / BK;
@@ -866,22 +934,18 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p);
             rc = vsx_check_launch("vsx_gemm_f16 (split-K reduce)");
         }
-    } else if (d->K <= 320 && cols % 160 == 0 && !p.geglu && blocks(128, 160) >= 512) {
-        // K = 320 projections are latency/HBM-bound (10 slabs per tile): two 4-wave workgroups per CU overlap one
-        // tile's epilogue with the other's loads (measured 101 vs 111 us with residual, 82 vs 86 us without).
-        rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);
-    } else if (wide && d->K >= 640 && blocks(256, 320) >= 240 &&
-               !(p.residual && p.vec4 && !p.geglu && d->K <= 1280)) {
-        // (residual epilogues with K <= 1280 go to the 8-wave tile below: it has the registers to prefetch the
-        // residual quads behind the first operand slabs; 76 vs 90 us at M=32768, N=K=640)
-        // 16 waves (1024 threads, 4 per SIMD), 32x160 per wave: 142 FLOP per staged byte — operand delivery into the
-        // CU (~7.5 TB/s aggregate measured) is what bounds these kernels, so the tile is as large as LDS allows.
-        // Short K loops (K = 320) stay on the 128-row tile: more, smaller workgroups overlap their pro/epilogues.
+    } else if (wide && blocks(256, 320) >= 240 && (p.a_mode == 1 || p.geglu || p.residual == nullptr)) {
+        // 16 waves (4 per SIMD), 32x160 per wave, 142 FLOP per staged byte: the big-M convolutions, the GEGLU
+        // projections (their erf epilogue overlaps with the other waves' MFMAs) and the residual-free projections.
+        // Measured per shape against the 8- and 4-wave tiles with tools/shape_prof.py (VSX_TUNE_TILE=1|2|3).
         rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
+    } else if (cols % 160 == 0 && blocks(128, 160) >= 200) {
+        // 4 waves, 32x160 per wave, two workgroups per CU (74 KiB of LDS each): one's epilogue and prologue overlap
+        // with the other's main loop, and its registers leave room to prefetch the residual.  Since the 128-byte-row
+        // slabs it is at least as fast as the 8-wave 128x320 tile on every UNet shape.
+        rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);
     } else if (wide && blocks(128, 320) >= 200) {
         rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);    // 8 waves, 32x160 per wave
-    } else if (cols % 160 == 0 && blocks(128, 160) >= 200) {
-        rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);    // 4 waves, 32x160 per wave, 2 WG per CU
     } else if (blocks(128, 128) >= 512) {
         rc = launch_tile<128, 128, 2, 2>(p, d->M, cols, nbatch, stream);
     } else if (blocks(64, 128) >= 512 || (p.geglu && cols >= 128)) {
