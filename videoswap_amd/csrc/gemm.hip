@@ -456,6 +456,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             mma(af1, bf1);
         }
     } else {
+        const bool late16 = NW >= 16 && ((wave >> 2) & 1);
 #ifdef VSX_GEMM_TIMING
         t_last = (long)clock64();
 #endif
@@ -464,7 +465,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             TSTAMP(1);
             __builtin_amdgcn_s_barrier();   // everybody's part of slab kt is in LDS; slot (kt-1)%NSTAGE is free
             TSTAMP(2);
-            if (kt + PREFETCH < nloc) issue(kt_begin + kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
+            // half of the waves of every SIMD (w>>2 even) stage right after the barrier, the other half one k-step
+            // later: the CU's DMA queue is fed by 8 waves at a time while the other 8 keep the matrix pipes busy
+            i_on = kt + PREFETCH < nloc;
+            i_gate = true;
+            if (i_on) issue_prep(kt_begin + kt + PREFETCH, (kt + PREFETCH) & (NSTAGE - 1));
+            if (!late16) {
+#pragma unroll
+                for (int q = 0; q < NPIECE; ++q) issue_piece(q);
+            }
             TSTAMP(3);
             const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
 #pragma unroll
@@ -472,6 +481,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                 h8 af[TM], bf[TN];
                 ldfrag(sb, offs[ks], af, bf);
                 mma(af, bf);
+                if (ks == 0 && late16) {
+#pragma unroll
+                    for (int q = 0; q < NPIECE; ++q) issue_piece(q);
+                }
             }
             TSTAMP(0);
         }
