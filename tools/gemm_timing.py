@@ -71,5 +71,44 @@ def run(M, N, K, iters=5):
 if __name__ == '__main__':
     if sys.argv[1] == 'build':
         build()
-    else:
+    elif sys.argv[1] == 'run':
         run(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
+
+
+def run_attn(nb, heads, nq, nk, d):
+    import torch
+    from videoswap_amd import _lib, ops
+    _lib.LIB_PATH = LIB
+    lib = _lib.load()
+    C = heads * d
+    q = torch.randn(nb, nq, C, device='cuda', dtype=torch.float16)
+    k = torch.randn(nb, nk, C, device='cuda', dtype=torch.float16)
+    v = torch.randn(nb, nk, C, device='cuda', dtype=torch.float16)
+    nblk = ((nq + 127) // 128) * heads * nb
+    dbg = torch.zeros(nblk * 4 * 6, dtype=torch.int64, device='cuda')
+    lib.vsx_attn_debug_buffer.restype = ctypes.c_int
+    lib.vsx_attn_debug_buffer.argtypes = [ctypes.c_void_p]
+    assert lib.vsx_attn_debug_buffer(ctypes.c_void_p(dbg.data_ptr())) == 0
+    wv = torch.randn(C, C, device='cuda', dtype=torch.float16) * 0.05
+    vt = ops.linear_vt(v.view(-1, C), wv, None, nk)      # [nb, C, ld] V^T
+    for _ in range(3):
+        out = ops.attention(q, k, vt, heads, d ** -0.5)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = ops.attention(q, k, vt, heads, d ** -0.5)
+    b.record(); b.synchronize()
+    us = a.elapsed_time(b) * 1e3
+    t = dbg.view(nblk, 4, 6).double()
+    nit = (nk + 63) // 64
+    per = t.mean(dim=(0, 1)) / nit
+    tot = per.sum().item()
+    names = ['wait: K/V tile landed', 'wait: barrier', 'DMA issue', 'S^T = K Q^T (MFMA)', 'online softmax (VALU)', 'O^T += V^T P^T (MFMA)']
+    print(f'attention nb={nb} heads={heads} nq={nq} nk={nk} d={d}: {us:.1f} us, {4.0 * nb * nq * nk * C / us / 1e6:.0f} TFLOP/s; '
+          f'cycles per 64-key tile (mean over waves): {tot:.0f}')
+    for n, x in zip(names, per.tolist()):
+        print(f'    {n:28s} {x:8.0f} cyc  {100 * x / tot:5.1f}%')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'attn':
+    run_attn(*[int(x) for x in sys.argv[2:7]])

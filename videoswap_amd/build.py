@@ -20,7 +20,10 @@ LIB = os.path.join(LIBDIR, 'libvsx.so')
 SOURCES = ['api.cpp', 'gemm.hip', 'norm.hip', 'attention.hip', 'elementwise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
-         '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-Wall', '-Wno-unused-function']
+         '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-Wall', '-Wno-unused-function', '-Wno-division-by-zero',
+         # MFMA results stay in architectural VGPRs: the attention kernels post-process every score on the VALU, and the
+         # default AGPR form cost 159 v_accvgpr_read/write moves per 64-key tile (measured in the ISA)
+         '-mllvm', '-amdgpu-mfma-vgpr-form']
 
 
 def _digest():

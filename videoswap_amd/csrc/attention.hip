@@ -33,6 +33,14 @@ struct AttnParams {
     float scale_log2e;
 };
 
+// -DVSX_GEMM_TIMING (tools/gemm_timing.py): per-wave cycle totals of the key-loop segments, long[block][wave][6]
+#ifdef VSX_GEMM_TIMING
+__device__ long* g_attn_dbg = nullptr;
+#define ASTAMP(i) do { const long t_now = (long)clock64(); t_seg[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+
 constexpr int KV_TILE = 64;
 constexpr int VSTR = 72;          // V^T LDS row: 64 keys + one 16-byte dummy slot (odd slot count)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -99,7 +107,11 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     for (int i = 0; i < NKI; ++i) {
         const int u = (wave * NKI + i) * 64 + lane;
         const int row = u / KSPR, slot = u - row * KSPR;
-        vk[i] = (u < K_UNITS && slot * 8 < D) ? (int)(((long)row * p.ldk + slot * 8) * 2) : OOB_OFF;
+        // LDS row r of the K tile holds key krow(r) = r with bits 2 and 3 swapped: in the 32x32 C/D layout a lane then
+        // owns 8 CONSECUTIVE keys per (tile, half) instead of two groups of 4, so the matching V^T fragment of the
+        // second product is one ds_read_b128
+        const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
+        vk[i] = (u < K_UNITS && slot * 8 < D) ? (int)(((long)key * p.ldk + slot * 8) * 2) : OOB_OFF;
     }
 #pragma unroll
     for (int i = 0; i < NVI; ++i) {
@@ -128,7 +140,10 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         for (int i = 0; i < NKI; ++i)
             if ((wave * NKI + i) * 64 < K_UNITS) {     // wave-uniform
                 int v = vk[i];
-                if (partial && j0 + ((wave * NKI + i) * 64 + lane) / KSPR >= p.nk) v = OOB_OFF;
+                if (partial) {
+                    const int row = ((wave * NKI + i) * 64 + lane) / KSPR;
+                    if (j0 + ((row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1)) >= p.nk) v = OOB_OFF;
+                }
                 // lanes past the end of the tile are switched off (EXEC): a DMA lane always writes its 16 bytes,
                 // zeros included, and would clobber the neighbouring LDS region
                 if ((wave * NKI + i) * 64 + lane < K_UNITS)
@@ -159,10 +174,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 
     issue(0, 0);
     int stage = 0;
+#ifdef VSX_GEMM_TIMING
+    long t_seg[6] = {0, 0, 0, 0, 0, 0}, t_last = (long)clock64();
+#endif
     for (int j0 = 0; j0 < p.nk; j0 += KV_TILE, stage ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ASTAMP(0);
         __syncthreads();   // tile j0 is in LDS for every wave; the other slot is no longer being read
+        ASTAMP(1);
         if (j0 + KV_TILE < p.nk) issue(j0 + KV_TILE, stage ^ 1);
+        ASTAMP(2);
         const half_t* sK = reinterpret_cast<const half_t*>(smem + stage * STAGE);
         const half_t* sV = reinterpret_cast<const half_t*>(smem + stage * STAGE + K_BYTES);
 
@@ -170,22 +191,23 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         f16v s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
             const half_t* krow = sK + (kt * 32 + l31) * KSTR + hi * 8;
+            const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < DK; ++t) {
                 const h8 kf = *reinterpret_cast<const h8*>(krow + t * 16);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t], s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t], t == 0 ? zero : s[kt], 0, 0, 0);
             }
         }
+        ASTAMP(3);
         // ---- online softmax (lane-local per query column); VALU budget: max3, fma, exp2, cvt per score ----
         if (j0 + KV_TILE > p.nk) {   // only the last, partial key tile needs masking (wave-uniform branch)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = j0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    // C/D row (r&3) + 8*(r>>2) + 4*hi of the tile holds key (r&3) + 4*((r>>2)&1) + 8*hi + 16*(r>>3)
+                    const int key = j0 + kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
                     if (key >= p.nk) s[kt][r] = -INFINITY;
                 }
         }
@@ -218,8 +240,9 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
             l_i += rs;
         }
 
+        ASTAMP(4);
         // ---- O^T += V^T P^T ----
-        // B operand k-slot jj of (kt, s2) on lane hi carries key kt*32 + 16*s2 + 8*(jj>>2) + 4*hi + (jj&3)
+        // B operand k-slot jj of (kt, s2) on lane hi carries key kt*32 + 16*s2 + 8*hi + jj (K rows are permuted)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -227,21 +250,23 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
                 h8 pf;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)s[kt][8 * s2 + jj];
-                const int c0 = kt * 32 + 16 * s2 + 4 * hi;
+                const int c0 = kt * 32 + 16 * s2 + 8 * hi;
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
-                    const half_t* vrow = sV + (t * 32 + l31) * VSTR + c0;
-                    const h4 va = *reinterpret_cast<const h4*>(vrow);
-                    const h4 vb = *reinterpret_cast<const h4*>(vrow + 8);
-                    h8 vf;
-                    vf[0] = va[0]; vf[1] = va[1]; vf[2] = va[2]; vf[3] = va[3];
-                    vf[4] = vb[0]; vf[5] = vb[1]; vf[6] = vb[2]; vf[7] = vb[3];
+                    const h8 vf = *reinterpret_cast<const h8*>(sV + (t * 32 + l31) * VSTR + c0);
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
                 }
             }
         }
+        ASTAMP(5);
     }
 
+#ifdef VSX_GEMM_TIMING
+    if (lane == 0 && g_attn_dbg) {
+        long* o_dbg = g_attn_dbg + ((long)blockIdx.x * 4 + wave) * 6;
+        for (int k = 0; k < 6; ++k) o_dbg[k] = t_seg[k];
+    }
+#endif
     if (HAS_SPARE) {
         // the denominator sits in the last row (31) of the last O^T tile: register 15 of the lanes with hi == 1;
         // broadcast it to the lane pair
@@ -371,6 +396,12 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempParams p) 
 }
 
 }  // namespace
+
+#ifdef VSX_GEMM_TIMING
+extern "C" int vsx_attn_debug_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int vsx_attention_f16(const void* Q, const void* K, const void* VT, void* O, int64_t nb, int64_t heads,
                                  int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk, int64_t ldvt,
