@@ -63,7 +63,8 @@ typedef struct vsx_gemm_desc {
     int64_t lda, a_bs0, a_bs1;
     int64_t a_mode;      /* 0 = plain rows, 1 = implicit im2col of a ks x ks conv, pad ks/2 */
     int64_t H, W;        /* a_mode 1: logical input height/width (after the optional 2x upsample) */
-    int64_t C1, C2;      /* a_mode 1: channels of A and A2 (C2 = 0 without A2); K = ks*ks*(C1+C2) */
+    int64_t C1, C2;      /* a_mode 1: channels of A and A2 (C2 = 0 without A2); K = ks*ks*(C1+C2).  Multiples of 8;
+                            with A2 both must be multiples of 64 (one K slab never straddles the two sources) */
     int64_t ks, stride;  /* a_mode 1: kernel size 1 or 3, stride 1 or 2 */
     int64_t upsample;    /* a_mode 1: 1 = A/A2 are [.., H/2, W/2, C], read as nearest-2x upsampled */
 

@@ -15,8 +15,9 @@
 // V arrives pre-transposed per image (vsx_gemm_f16 c_mode 1 writes V^T while projecting), which
 // keeps every LDS fragment read a contiguous 8/16-byte access.
 //
-// LDS: K tile [64][DK*16+8] halfs (row = 2*DK+1 16-byte slots, odd => conflict-free b128 reads),
-//      V^T tile [DT*32][68] halfs (136-byte rows => conflict-free b64 reads).
+// LDS: K tile [64][DK*16+8] halfs (row = 2*DK+1 16-byte slots, odd => conflict-free b128 reads); LDS row r holds key
+//      r with bits 2,3 swapped, which makes a lane's 8 scores per MFMA step 8 consecutive keys;
+//      V^T tile [DT*32][72] halfs (144-byte rows = 9 slots, odd => conflict-free b128 reads).
 #include "common.h"
 
 namespace {

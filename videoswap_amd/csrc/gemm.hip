@@ -3,19 +3,21 @@
 //   C[m, n] = epilogue(alpha * sum_k A[m, k] * B[n, k])
 //
 // Design (CDNA4):
-//  * v_mfma_f32_32x32x16_f16, fp32 accumulators.  Workgroup = WAVES_M x WAVES_N wave64; the flagship tiles are
-//    256x320 (8 waves) and 128x320 (4 waves): every wave owns a 64x160 sub-tile (2x5 MFMA tiles, 10 MFMAs per 7
-//    fragment reads).  N = 320 divides every channel count of the SD-1.5 UNet (320/640/1280 and the 2560/5120/10240
-//    GEGLU rows), so no MFMA work is wasted on column padding and the A row-panel — the big operand — is read once
-//    per 320 output columns instead of once per 128.  128x128 / 64x128 / 64x64 tiles cover small or odd problems.
-//  * Operand staging is LDS-DMA (`buffer_load_dwordx4 ... offen lds`): no VGPR round trip, no ds_write.  A ring of
-//    NSTAGE = 4 LDS slots of BK = 32 is kept PREFETCH = 3 slabs ahead with COUNTED `s_waitcnt vmcnt(N)` and one raw
-//    `s_barrier` per slab (slab kt+3 is issued right after the barrier that retires slot (kt-1) % 4).
+//  * v_mfma_f32_32x32x16_f16, fp32 accumulators.  Workgroup = WAVES_M x WAVES_N wave64, every wave owns a 32x160 (or
+//    smaller) sub-tile: 256x320 (16 waves), 128x320 (8), 128x160 (4, two workgroups per CU), 128x128 / 64x128 / 64x64.
+//    N = 320 divides every channel count of the SD-1.5 UNet (320/640/1280 and the 2560/5120/10240 GEGLU rows), so no
+//    MFMA work is wasted on column padding.
+//  * Operand staging is LDS-DMA (`buffer_load_dwordx4 ... offen lds`): no VGPR round trip, no ds_write.  K advances in
+//    slabs of BK = 64 halfs, so every row contributes one full 128-byte L2 line per slab (64-byte half lines capped the
+//    L2 -> LDS stream at 11.5 TB/s chip-wide, full lines reach 17-24 TB/s: tools/ubench/stage2.hip).  Ring of 2 slabs
+//    for the big tiles, 4 for the small ones, COUNTED `s_waitcnt vmcnt(N)` and one raw `s_barrier` per slab.
 //  * Buffer descriptors do the edge handling: a row's per-lane byte offset is loop-invariant, K advances in the
-//    scalar offset, and an out-of-range offset makes the hardware return zeros (M/N edges, conv zero padding).
-//  * LDS rows are 64 B (4 x 16-B slots) XOR-swizzled with (row >> 2) & 3; the DMA destination must be lane-linear,
+//    scalar offset, and an out-of-range offset makes the hardware return zeros (M/N edges, conv zero padding, K tail).
+//  * LDS rows are 128 B (8 x 16-B slots) XOR-swizzled with (row >> 1) & 7; the DMA destination must be lane-linear,
 //    so the swizzle is applied to the SOURCE column of each lane and again when fragments are read: conflict-free
-//    ds_read_b128 (SQ_LDS_BANK_CONFLICT = 0 measured).
+//    ds_read_b128 in the hardware's 16-lane groups.
+//  * Main loop: fragments are register-double-buffered across the four k-steps of a slab, a slab's 1-KiB DMA pieces
+//    are issued one at a time between MFMAs, and the two waves of a SIMD stage in different k-steps.
 //  * Workgroup ids are remapped so that each XCD (own L2) walks a contiguous range of tiles.
 //
 // The A operand has two loaders:
@@ -36,9 +38,7 @@
 namespace {
 
 constexpr int BK = 64;          // K slab (halfs); LDS rows are 128 B = 8 16-byte slots = one full L2 line per row
-// LDS ring depth NSTAGE is a template parameter: 4 slots (3 slabs in flight) for long K loops; 2 slots for short ones
-// (K <= 640), where halving the LDS footprint lets two workgroups share a CU and overlap one's prologue / epilogue
-// with the other's main loop — the dominant cost when the loop is only 10-20 slabs long
+// LDS ring depth NSTAGE is a template parameter: 2 slots for the big tiles (57-74 KiB per slab), 4 for the small ones
 
 struct GemmParams {
     const half_t* A;
