@@ -195,7 +195,9 @@ int vsx_adapter_scatter(const float* tracks, const int32_t* selected, const void
 
 /* ------------------------------------------------------------------------------------------
  * Launch-time instrumentation used by bench.py: when enabled, vsx_gemm_f16 brackets each of its
- * launches with hipEvents on the launch stream (at most `max_samples` launches are sampled).
+ * launches with hipEvents on the launch stream (at most `max_samples` launches are sampled;
+ * on = k > 1 brackets every k-th launch only: the two event packets cost a few microseconds per
+ * launch, 5 % of the whole loop when every launch is bracketed).
  * vsx_prof_collect synchronises those events and returns the number of sampled launches, their
  * summed duration (ms) and summed algorithmic FLOP (2*M*N*K*batch; geglu counts B's 2N rows).
  * ------------------------------------------------------------------------------------------ */

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .layers import Identity, Linear
+from .layers import Identity, Linear, StepInvariantCache
 
 
 class Attention(nn.Module):
@@ -117,17 +117,27 @@ class Attention(nn.Module):
 def _project_kv(attn, hidden_states, encoder_hidden_states, layer_idx=None):
     """K [nkvb, nk, C] and V^T [nkvb, C, ld] of the context (self: the tokens; cross: the text, with the ED-LoRA
     per-layer slice `[:, layer_idx]` of a [.., 16, 77, 768] embedding: edlora_util.py:39-43)."""
+    def project(ctx):
+        nkvb, nk, _ = ctx.shape
+        k = attn.to_k(ctx)
+        vt = ops.linear_vt(ctx.reshape(nkvb * nk, ctx.shape[-1]), attn.to_v.weight, attn.to_v.bias, nk)
+        return k, vt, nk
+
     if encoder_hidden_states is None:
-        ctx = hidden_states
-    else:
+        return project(hidden_states)
+
+    def from_text():
         ctx = encoder_hidden_states
         if ctx.dim() == 4:
             ctx = ctx[:, 0 if layer_idx is None else layer_idx]
-        ctx = ctx.contiguous()
-    nkvb, nk, _ = ctx.shape
-    k = attn.to_k(ctx)
-    vt = ops.linear_vt(ctx.reshape(nkvb * nk, ctx.shape[-1]), attn.to_v.weight, attn.to_v.bias, nk)
-    return k, vt, nk
+        return project(ctx.contiguous())
+
+    # the text embedding is the same tensor in every denoising step: its K / V^T are step-invariant
+    cache = attn.__dict__.get('_text_kv')
+    if cache is None:
+        cache = attn.__dict__['_text_kv'] = StepInvariantCache(limit=8)
+    return cache.get(encoder_hidden_states, layer_idx,
+                     (attn.to_k.weight, attn.to_k.bias, attn.to_v.weight, attn.to_v.bias), from_text)
 
 
 class _FusedProcessor:

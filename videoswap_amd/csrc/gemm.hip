@@ -752,6 +752,7 @@ int launch_tile(GemmParams& p, long M, long cols, long nbatch, hipStream_t strea
 struct ProfState {
     bool on = false;
     long max_samples = 0;
+    long stride = 1, seen = 0;
     long n = 0;
     double flop = 0.0;
     std::vector<hipEvent_t>* ev = nullptr;  // 2 per sample
@@ -764,6 +765,8 @@ ProfState g_prof;
 extern "C" int vsx_prof_enable(int64_t on, int64_t max_samples) {
     if (!g_prof.ev) g_prof.ev = new std::vector<hipEvent_t>();
     g_prof.on = on != 0;
+    g_prof.stride = on > 1 ? on : 1;        // on = k > 1: bracket every k-th launch only
+    g_prof.seen = 0;
     g_prof.max_samples = max_samples;
     g_prof.n = 0;
     g_prof.flop = 0.0;
@@ -914,7 +917,7 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     auto blocks = [&](long bm, long bn) { return ((d->M + bm - 1) / bm) * ((cols + bn - 1) / bn) * nbatch; };
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool sample = g_prof.on && g_prof.n < g_prof.max_samples;
+    const bool sample = g_prof.on && g_prof.n < g_prof.max_samples && (g_prof.seen++ % g_prof.stride) == 0;
     if (sample) {
         if ((long)g_prof.ev->size() < 2 * (g_prof.n + 1)) {
             hipEvent_t a, b;

@@ -10,6 +10,35 @@ from torch import nn
 from . import ops
 
 
+def param_key(*params):
+    """Identity of a set of parameters for host-side caches: a LoRA merge / load_state_dict bumps `_version`,
+    .to()/.half() replace the storage."""
+    return tuple((p.data_ptr(), p._version, p.dtype) for p in params if p is not None)
+
+
+class StepInvariantCache:
+    """Results that depend only on an input TENSOR OBJECT (kept alive here, so its address cannot be recycled) and on
+    parameters: the text K/V projections and the time-embedding projections are identical in every denoising step
+    that passes the same embedding, so they are computed once per (input, parameters) instead of 100 x per clip —
+    about 70 launch-latency-bound M <= 154 GEMMs per UNet call."""
+
+    def __init__(self, limit=256):
+        self.limit = limit
+        self.entries = {}
+
+    def get(self, src, extra, params, fn):
+        key = (id(src), extra)
+        hit = self.entries.get(key)
+        stamp = (src._version, param_key(*params))
+        if hit is not None and hit[0] is src and hit[1] == stamp:
+            return hit[2]
+        val = fn()
+        if len(self.entries) >= self.limit:
+            self.entries.clear()
+        self.entries[key] = (src, stamp, val)
+        return val
+
+
 class Linear(nn.Linear):
     """y = x W^T + b on the MFMA GEMM; optional fused residual add."""
 

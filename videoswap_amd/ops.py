@@ -410,8 +410,9 @@ def adapter_scatter(tracks, selected, feat, h, w, rate, out_scale=1.0):
     return out
 
 
-def prof_enable(on, max_samples=4096):
-    check(_lib.load().vsx_prof_enable(1 if on else 0, max_samples), 'vsx_prof_enable')
+def prof_enable(on, max_samples=4096, stride=1):
+    """Bracket every `stride`-th vsx_gemm_f16 launch with hipEvents (bench.py's roofline object)."""
+    check(_lib.load().vsx_prof_enable((max(int(stride), 1) if on else 0), max_samples), 'vsx_prof_enable')
 
 
 def prof_collect():
