@@ -125,7 +125,7 @@ def main():
     barrier()
 
     ops.FlopCounter.reset(True)
-    ops.prof_enable(True, args.prof_samples)
+    ops.prof_enable(args.prof_samples > 0, args.prof_samples, stride=args.prof_stride)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_clip(pipe, clips[i % len(clips)], args.ddim_steps)

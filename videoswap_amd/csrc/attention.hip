@@ -339,15 +339,49 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempParams p) 
     const long b = blockIdx.z;
     const int dv = d >> 3;
 
-    for (int i = lane; i < fq * dv; i += 64) {
-        const int f = i / dv, c = (i - f * dv) * 8;
-        st16(sQ + f * d + c, ld16(p.Q + ((b * fq + f) * p.hw + site) * p.ldq + h * d + c));
+    // Stage Q, K, V: all of a batch's global loads are issued before the first LDS store (the loop used to wait for
+    // every 16-byte load before issuing the next one: one or two requests in flight per wave, 2 TB/s)
+    constexpr int UB = 4;
+    for (int i0 = lane; i0 < fq * dv; i0 += 64 * UB) {
+        uint4 r[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < fq * dv) {
+                const int f = i / dv, c = (i - f * dv) * 8;
+                r[u] = ld16(p.Q + ((b * fq + f) * p.hw + site) * p.ldq + h * d + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < fq * dv) {
+                const int f = i / dv, c = (i - f * dv) * 8;
+                st16(sQ + f * d + c, r[u]);
+            }
+        }
     }
-    for (int i = lane; i < fk * dv; i += 64) {
-        const int f = i / dv, c = (i - f * dv) * 8;
-        const long row = (b * fk + f) * p.hw + site;
-        st16(sK + f * d + c, ld16(p.K + row * p.ldkv + h * d + c));
-        st16(sV + f * d + c, ld16(p.V + row * p.ldkv + h * d + c));
+    for (int i0 = lane; i0 < fk * dv; i0 += 64 * UB) {
+        uint4 rk[UB], rv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < fk * dv) {
+                const int f = i / dv, c = (i - f * dv) * 8;
+                const long row = (b * fk + f) * p.hw + site;
+                rk[u] = ld16(p.K + row * p.ldkv + h * d + c);
+                rv[u] = ld16(p.V + row * p.ldkv + h * d + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < fk * dv) {
+                const int f = i / dv, c = (i - f * dv) * 8;
+                st16(sK + f * d + c, rk[u]);
+                st16(sV + f * d + c, rv[u]);
+            }
+        }
     }
     __syncthreads();
     for (int i = lane; i < fq * fk; i += 64) {
