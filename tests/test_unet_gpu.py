@@ -79,3 +79,39 @@ def test_zero_initialised_motion_module_is_identity(setup):
     with torch.no_grad():
         y = mm(x, Geometry(2, 4))
     assert torch.equal(x, y)
+
+
+def test_step_invariant_caches_follow_inputs_and_weights(setup):
+    """The text K/V and time-embedding caches must be invisible: same results with cold and warm caches, and an
+    in-place edit of the text embedding or a weight reload is picked up."""
+    blob, ora, prod = setup
+    case = blob['cases']['plain_T4_16x16']
+    x, txt = case['sample'].half().cuda(), case['text'].half().cuda()
+    with torch.no_grad():
+        prod.clear_step_caches()
+        cold = prod(x, 481, txt).sample
+        warm = prod(x, 481, txt).sample                      # every cache hits
+        assert torch.equal(cold, warm)
+        txt2 = txt.clone()
+        ref2 = prod(x, 481, txt2 * 0.5).sample               # what an uncached forward gives for the scaled text
+        txt2.mul_(0.5)                                        # same tensor object, new contents
+        a = prod(x, 481, txt2).sample
+        b = prod(x, 481, txt2).sample
+        assert torch.equal(a, ref2) and torch.equal(a, b)
+        assert not torch.equal(a, cold)
+        # weights: scale one text-K projection and one time-embedding projection in place (load_state_dict style)
+        sd = {k: v.clone() for k, v in prod.state_dict().items()}
+        kname = next(k for k in sd if k.endswith('attn2.to_k.weight'))
+        tname = next(k for k in sd if k.endswith('time_emb_proj.weight'))
+        sd[kname] *= 1.5
+        sd[tname] *= 1.5
+        orig = {k: v.clone() for k, v in prod.state_dict().items()}
+        prod.load_state_dict(sd)
+        c = prod(x, 481, txt).sample
+        prod.clear_step_caches()
+        d = prod(x, 481, txt).sample
+        prod.load_state_dict(orig)
+        e = prod(x, 481, txt).sample
+    assert torch.equal(c, d), 'a weight reload must invalidate the cached projections'
+    assert not torch.equal(c, cold)
+    assert torch.equal(e, cold)
