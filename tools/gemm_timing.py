@@ -32,7 +32,7 @@ def run(M, N, K, iters=5):
     _lib.LIB_PATH = LIB
     lib = _lib.load()
     tile = int(os.environ.get('VSX_TUNE_TILE', '1'))
-    BM, BN, NW = {1: (128, 320, 8), 2: (128, 160, 4), 3: (256, 320, 16), 4: (256, 320, 8)}[tile]
+    BM, BN, NW = {1: (128, 320, 8), 2: (128, 160, 4), 3: (256, 320, 16)}[tile]
     x = torch.randn(M, K, device='cuda', dtype=torch.float16)
     w = torch.randn(N, K, device='cuda', dtype=torch.float16) * 0.02
     out = torch.empty(M, N, device='cuda', dtype=torch.float16)

@@ -9,8 +9,8 @@ from videoswap_amd import ops  # noqa: E402
 from tools.kbench import timeit  # noqa: E402
 
 tile = int(os.environ.get('VSX_TUNE_TILE', '1'))
-BM = {1: 128, 2: 128, 3: 256, 4: 256}[tile]
-BN = {1: 320, 2: 160, 3: 320, 4: 320}[tile]
+BM = {1: 128, 2: 128, 3: 256}[tile]
+BN = {1: 320, 2: 160, 3: 320}[tile]
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 w = torch.randn(320, K, device='cuda', dtype=torch.float16) * 0.01
 for tiles_m in (8, 16, 32, 64, 128, 256, 512):

@@ -792,7 +792,8 @@ extern "C" int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* t
     return VSX_OK;
 }
 
-// Diagnostics only (tools/tile_probe.py): VSX_TUNE_TILE=1|2|3 forces the 128x320 / 128x160 / 256x320 tile, no split-K.
+// Diagnostics only (tools/tile_probe.py, tools/gemm_timing.py): VSX_TUNE_TILE=1|2|3 forces the 128x320 / 128x160 /
+// 256x320 tile (no split-K) for problems whose column count is a multiple of 320.
 static long force_tile() {
     static long v = -1;
     if (v < 0) {
@@ -936,8 +937,7 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
         p.ws = (float*)d->workspace;
         if (force_tile() == 1) rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);
         else if (force_tile() == 2) rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);
-        else if (force_tile() == 3) rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
-        else rc = launch_tile<256, 320, 4, 2>(p, d->M, cols, nbatch, stream);
+        else rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
     } else if (splits > 1 && d->workspace != nullptr &&
         d->workspace_bytes >= (int64_t)splits * d->M * d->N * (int64_t)sizeof(float)) {
         const long nk = (d->K + BK - 1) / BK;
