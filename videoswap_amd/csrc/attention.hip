@@ -430,6 +430,143 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempParams p) 
     }
 }
 
+
+// K8 on the matrix cores.  A (site, head) problem is only fq x fk x d (16 x 16 x 40): G = 32 / max(fq, fk) problems —
+// consecutive heads of one site — are packed along BOTH dimensions of a 32x32 tile, S^T[(g,key), (g',query)], and the
+// off-diagonal blocks (g != g') are masked to zero probability, which makes P block-diagonal so that one
+// O^T[c, (g',query)] = V^T[c, (g,key)] . P^T product serves all packed problems.  Operands of the first product are
+// loaded straight from HBM into MFMA registers (a lane's 16 bytes = 8 consecutive channels of one (frame, head) row;
+// MFMA row r carries packed key swap23(r), so the exponentiated scores are already a B operand, as in the flash
+// kernel); V goes through a wave-private LDS tile, written transposed ([channel][key]) and read back as b128.
+// One wave per G heads, four waves (independent, no barriers) per workgroup.  The first version did these products
+// with per-lane dot products over LDS copies of Q, K, V and was VALU/LDS-bound at 2 TB/s.
+template <int D>
+__global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const TempParams p) {
+    constexpr int DK = (D + 15) / 16;      // k-steps of S^T = K Q^T
+    constexpr int DT = (D + 31) / 32;      // 32-row tiles of O^T
+    constexpr int DV = D / 8;              // 16-byte chunks per (frame, head) row
+    constexpr int VSTR = 40;               // V^T LDS row: 32 keys + 8 pad halfs (5 slots, odd)
+    constexpr int NVL = (32 * DV + 63) / 64;
+    __shared__ __attribute__((aligned(16))) half_t smem[4][DT * 32 * VSTR];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int fq = p.fq, fk = p.fk;
+    const int G = 32 / max(fq, fk);
+    const long site = blockIdx.x;
+    const long b = blockIdx.z;
+    const int head0 = ((int)blockIdx.y * 4 + wave) * G;
+    if (head0 >= p.heads) return;          // waves are independent: no barrier below
+    half_t* sVT = smem[wave];
+
+    // ---- V: coalesced 16-byte loads, transposed scatter into LDS (zeros for padding keys / heads) ----
+    {
+        uint4 raw[NVL];
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int u = lane + 64 * i;
+            const int key = u / DV, ch = u - key * DV;
+            const int g = key / fk, f = key - g * fk;
+            const bool ok = u < 32 * DV && g < G && head0 + g < p.heads;
+            raw[i] = ok ? ld16(p.V + ((b * fk + f) * p.hw + site) * p.ldkv + (long)(head0 + g) * D + ch * 8)
+                        : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int u = lane + 64 * i;
+            if (u < 32 * DV) {
+                const int key = u / DV, ch = u - key * DV;
+                const h8 v = as_h8(raw[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sVT[(ch * 8 + e) * VSTR + key] = v[e];
+            }
+        }
+    }
+
+    // ---- S^T = K Q^T: MFMA row r <- packed key swap23(r), column <- packed query ----
+    const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int kg = krow / fk, kf_ = krow - kg * fk;
+    const bool kok = kg < G && head0 + kg < p.heads;
+    const int qg = l31 / fq, qf_ = l31 - qg * fq;
+    const bool qok = qg < G && head0 + qg < p.heads;
+    const half_t* kptr = p.K + ((b * fk + kf_) * p.hw + site) * p.ldkv + (long)(head0 + kg) * D + hi * 8;
+    const half_t* qptr = p.Q + ((b * fq + qf_) * p.hw + site) * p.ldq + (long)(head0 + qg) * D + hi * 8;
+    h8 ka[DK], qb[DK];
+#pragma unroll
+    for (int t = 0; t < DK; ++t) {
+        const bool in = t * 16 + hi * 8 < D;
+        ka[t] = (kok && in) ? as_h8(ld16(kptr + t * 16)) : as_h8(make_uint4(0, 0, 0, 0));
+        qb[t] = (qok && in) ? as_h8(ld16(qptr + t * 16)) : as_h8(make_uint4(0, 0, 0, 0));
+    }
+    const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16v sc = zero;
+#pragma unroll
+    for (int t = 0; t < DK; ++t) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[t], qb[t], t == 0 ? zero : sc, 0, 0, 0);
+
+    // ---- softmax over the keys of this column's own problem (register r holds packed key (r&3)+4*((r>>2)&1)+8*hi+16*(r>>3)) ----
+    const int lo = qg * fk, up = lo + fk;
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
+        const bool v = qok && key >= lo && key < up;
+        sc[r] = v ? sc[r] * sl2 : -INFINITY;
+        mx = fmaxf(mx, sc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;         // padding column: every probability is exp2(-inf) = 0
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sc[r] = __builtin_amdgcn_exp2f(sc[r] - mx);
+        sum += sc[r];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+    // ---- O^T = V^T P^T (P block-diagonal, unnormalised, fp16; normalised in fp32 afterwards) ----
+    f16v o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = zero;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        h8 pf;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)sc[8 * s2 + jj];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const h8 vf = *reinterpret_cast<const h8*>(sVT + (t * 32 + l31) * VSTR + 16 * s2 + 8 * hi);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
+        }
+    }
+    if (qok) {
+        half_t* orow = p.O + ((b * fq + qf_) * p.hw + site) * p.ldo + (long)(head0 + qg) * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = t * 32 + 8 * g4 + 4 * hi;
+                if (c < D) {
+                    h4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g4 + e] * inv);
+                    *reinterpret_cast<h4*>(orow + c) = pk;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch_temporal_mfma(const TempParams& p, long B, hipStream_t stream) {
+    const int G = 32 / (p.fq > p.fk ? p.fq : p.fk);
+    const int groups = (p.heads + G - 1) / G;
+    dim3 grid((unsigned)p.hw, (unsigned)((groups + 3) / 4), (unsigned)B);
+    hipLaunchKernelGGL((temporal_attn_mfma_kernel<D>), grid, dim3(256), 0, stream, p);
+    return vsx_check_launch("vsx_temporal_attention_f16");
+}
+
 }  // namespace
 
 #ifdef VSX_GEMM_TIMING
@@ -490,6 +627,11 @@ extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const vo
     p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
     p.fq = (int)fq; p.fk = (int)fk; p.hw = (int)hw; p.heads = (int)heads; p.d = (int)d;
     p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.scale = scale;
+    if (fq <= 32 && fk <= 32) {            // matrix-core kernel for the UNet's head dims
+        if (d == 40) return launch_temporal_mfma<40>(p, B, (hipStream_t)stream);
+        if (d == 80) return launch_temporal_mfma<80>(p, B, (hipStream_t)stream);
+        if (d == 160) return launch_temporal_mfma<160>(p, B, (hipStream_t)stream);
+    }
     const size_t slice = (((size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float)) + 15) & ~(size_t)15;
     const size_t smem = 4 * slice;
     VSX_REQUIRE(smem <= 160 * 1024, VSX_E_UNSUPPORTED, "temporal_attention: %zu bytes of LDS needed (> 160 KiB)", smem);
