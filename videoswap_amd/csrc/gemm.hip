@@ -54,7 +54,7 @@ struct GemmParams {
     long c_rows_per_img, c_img_stride, rows_per_vec;
     int batch1;
     int a_mode, H, W, C1, C2, Ho, Wo, ks, stride, ups;
-    int geglu, c_mode, c_pack4, vec4;
+    int geglu, c_mode, c_pack4, vec4, vec8, rvec8;
     int tiles_n;
     unsigned a_bytes, a2_bytes, b_bytes;   // buffer extents (per batch slice) for the SRD bounds check
     int splitk, nk_per;                    // split-K: grid.z = splitk slices of nk_per slabs, fp32 partials to `ws`
@@ -327,7 +327,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             for (int i = 0; i < TM; ++i) {
                 const int m = (int)m0 + wr * WM + i * 32 + l31;
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
+                    if (p.rvec8 && (int)n0 + wc * WN + j * 32 + 31 < (int)p.N) {
+                        // full tile: two 16-byte loads in the epilogue's post-exchange layout (8 consecutive columns
+                        // per lane); the epilogue swaps them back into register-quad order
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            const int nc = (int)n0 + wc * WN + j * 32 + 16 * a + 8 * hi;
+                            uint4 v = make_uint4(0, 0, 0, 0);
+                            if (m < (int)p.M) v = *reinterpret_cast<const uint4*>(Rb0 + (unsigned)m * (unsigned)p.ldr + nc);
+                            rpre[(i * TN + j) * 4 + 2 * a] = __builtin_bit_cast(h4, make_uint2(v.x, v.y));
+                            rpre[(i * TN + j) * 4 + 2 * a + 1] = __builtin_bit_cast(h4, make_uint2(v.z, v.w));
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int nb = (int)n0 + wc * WN + j * 32 + 8 * g + 4 * hi;
@@ -336,6 +349,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             v = *reinterpret_cast<const h4*>(Rb0 + (unsigned)m * (unsigned)p.ldr + nb);
                         rpre[(i * TN + j) * 4 + g] = v;
                     }
+                }
             }
         }
     }
@@ -587,6 +601,75 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+                if (p.vec8 && nb0 + wc * WN + j * 32 + 31 < Ni) {
+                    // Full 32-column tile: the lane pair (l, l+32) exchanges register quads with v_permlane32_swap so
+                    // that each lane owns 8 consecutive columns and stores 16 bytes — two dwordx4 stores per tile and
+                    // lane instead of four dwordx2 (the epilogue is store-ISSUE-bound: every store instruction of the
+                    // row-per-lane layout touches 32 different rows).
+                    unsigned pkw[4][2];
+                    h4 rq[4];          // residual register quads (16-byte loads in the exchanged layout, swapped back)
+                    if (rrow && p.rvec8) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            uint2 lo2, hi2;
+                            if (PRE_RES && pre_res) {
+                                lo2 = __builtin_bit_cast(uint2, rpre[PRE_RES ? (i * TN + j) * 4 + 2 * a : 0]);
+                                hi2 = __builtin_bit_cast(uint2, rpre[PRE_RES ? (i * TN + j) * 4 + 2 * a + 1 : 0]);
+                            } else {
+                                const uint4 v = *reinterpret_cast<const uint4*>(rrow + nb0 + wc * WN + j * 32 + 16 * a + 8 * hi);
+                                lo2 = make_uint2(v.x, v.y);
+                                hi2 = make_uint2(v.z, v.w);
+                            }
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(lo2.x, hi2.x, false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(lo2.y, hi2.y, false, false);
+                            rq[2 * a] = __builtin_bit_cast(h4, make_uint2(s0[0], s1[0]));
+                            rq[2 * a + 1] = __builtin_bit_cast(h4, make_uint2(s0[1], s1[1]));
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = nb0 + wc * WN + j * 32 + 8 * g + 4 * hi;
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[j][i][4 * g + e] * p.alpha;
+                        if (p.bias) {
+                            const h4 b = *reinterpret_cast<const h4*>(p.bias + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
+                        }
+                        if (rv) {
+                            const h4 b = *reinterpret_cast<const h4*>(rv + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
+                        }
+                        if (rrow) {
+                            h4 b;
+                            if (p.rvec8) b = rq[g];
+                            else if (PRE_RES && pre_res) b = rpre[PRE_RES ? (i * TN + j) * 4 + g : 0];
+                            else b = *reinterpret_cast<const h4*>(rrow + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
+                        }
+                        h4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (half_t)o[e];
+                        const uint2 w = __builtin_bit_cast(uint2, pk);
+                        pkw[g][0] = w.x;
+                        pkw[g][1] = w.y;
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        // quads 2a (columns 16a + 4hi ..) and 2a+1 (16a + 8 + 4hi ..): after the swap the lower lane
+                        // of the pair holds columns 16a .. 16a+7, the upper lane 16a+8 .. 16a+15
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(pkw[2 * a][0], pkw[2 * a + 1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(pkw[2 * a][1], pkw[2 * a + 1][1], false, false);
+                        const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        const int nc = nb0 + wc * WN + j * 32 + 16 * a + 8 * hi;
+                        *reinterpret_cast<uint4*>(crow + nc) = out;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int nb = nb0 + wc * WN + j * 32 + 8 * g + 4 * hi;
@@ -911,6 +994,11 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
               al8(d->rowvec) && d->N % 4 == 0 &&
               (!d->residual || (al8(d->residual) && d->ldr % 4 == 0 && d->r_bs0 % 4 == 0 && d->r_bs1 % 4 == 0)))
                  ? 1 : 0;
+    // 16-byte stores (two lanes of a pair exchange register quads first) when rows and column octets are 16-byte aligned
+    auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    p.vec8 = (p.vec4 && d->ldc % 8 == 0 && d->c_bs0 % 8 == 0 && d->c_bs1 % 8 == 0 && al16(d->C) && d->N % 8 == 0) ? 1 : 0;
+    p.rvec8 = (p.vec8 && d->residual && al16(d->residual) && d->ldr % 8 == 0 && d->r_bs0 % 8 == 0 && d->r_bs1 % 8 == 0)
+                  ? 1 : 0;
 
     // tile selection.  cols = rows of B.  The 320-wide tiles need cols % 320 == 0 (no column padding waste) and
     // enough workgroups to cover the 256 CUs; otherwise fall back to the 128/64 tiles (2 workgroups per CU).
