@@ -42,6 +42,9 @@ typedef void* vsx_stream_t; /* hipStream_t */
 
 int vsx_abi_version(void);
 const char* vsx_last_error(void);
+/* sha256 (hex) of the kernel sources + flags the library was built from; the Python loader compares it with the
+ * sources it sits next to and refuses a stale binary. */
+const char* vsx_source_digest(void);
 
 /* ------------------------------------------------------------------------------------------
  * K1/K2: MFMA GEMM / implicit-GEMM convolution with fused epilogues.

@@ -382,8 +382,8 @@ class DDIMInverseScheduler:
 
     Chosen variant = the 0.17-0.19 one: `set_timesteps` builds the leading-spaced ascending grid
     1, 21, ..., 981 (steps_offset 1), rolls it by one and sets timesteps[0] = timesteps[1] - step_ratio, giving
-    -19, 1, 21, ..., 961; `step` moves x_t -> x_{t + step_ratio} with alpha_bar_t = 1 for the negative first
-    timestep (`initial_alpha_cumprod`).  The last step therefore lands on t = 981, exactly the first timestep of
+    -19, 1, 21, ..., 961; `step` moves x_t -> x_{t + step_ratio} with alpha_bar_t = `initial_alpha_cumprod` for the
+    negative first timestep (1 when `set_alpha_to_one`, else alphas_cumprod[0]; SD-1.5: 0.99915).  The last step therefore lands on t = 981, exactly the first timestep of
     the DDIM sampler that consumes the inverted latents (pipeline_videoswap.py:503-518).
     """
     order = 1
@@ -397,7 +397,8 @@ class DDIMInverseScheduler:
                                  prediction_type=prediction_type, timestep_spacing=timestep_spacing)
         assert prediction_type == 'epsilon' and timestep_spacing == 'leading'
         self.alphas_cumprod = _alphas_cumprod(num_train_timesteps, beta_start, beta_end, beta_schedule)
-        self.initial_alpha_cumprod = torch.tensor(1.0)
+        # diffusers 0.18-0.19: `initial_alpha_cumprod = 1.0 if set_alpha_to_one else alphas_cumprod[0]`
+        self.initial_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
         self.init_noise_sigma = 1.0
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps).copy().astype(np.int64))

@@ -25,12 +25,25 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(torch.float16).to(DEV)
 
 
-def rel_err(out, ref):
+def rel_err(out, ref, l2_tol=1.5e-3, row_tol=6e-3):
+    """Returns max|d| / max|ref| (the caller's threshold) and ASSERTS two metrics the max-norm cannot see:
+    the rel-L2 error of the whole tensor (a wrong low-magnitude region) and the worst per-row rel-L2 error
+    (one bad tile edge / one bad row of an otherwise fine tensor; rows = the last axis, rows whose reference norm is
+    below 10 % of the mean row norm are measured against that floor).  An fp16-rounded exact result sits at
+    rel-L2 ~3e-4."""
     out = out.float()
     ref = ref.float()
     assert out.shape == ref.shape, f'shape {tuple(out.shape)} vs {tuple(ref.shape)}'
     assert torch.isfinite(out).all(), 'non-finite values in kernel output'
-    return ((out - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+    d = (out - ref).double()
+    r = ref.double()
+    l2 = (d.norm() / r.norm().clamp_min(1e-12)).item()
+    assert l2 < l2_tol, f'rel-L2 {l2:.3e} >= {l2_tol:.1e}'
+    if ref.dim() >= 2 and ref.shape[-1] >= 8:
+        dr, rr = d.reshape(-1, d.shape[-1]).norm(dim=1), r.reshape(-1, r.shape[-1]).norm(dim=1)
+        row = (dr / rr.clamp_min(0.1 * rr.mean().clamp_min(1e-12))).max().item()
+        assert row < row_tol, f'worst row rel-L2 {row:.3e} >= {row_tol:.1e} (tensor rel-L2 {l2:.3e})'
+    return (d.abs().max() / r.abs().max().clamp_min(1e-6)).item()
 
 
 # --------------------------------------------------------------------------------------------
@@ -88,6 +101,14 @@ def conv_ref(x, w, b, stride, x2=None, upsample=False):
     (2, 16, 16, 128, 64, 96, 1, 1, False),   # 1x1 shortcut on a concat
     (4, 64, 64, 320, 0, 320, 3, 1, False),   # big-tile path
     (2, 14, 24, 320, 0, 4, 3, 1, False),     # conv_out-like (N = 4)
+    # M >= 61 440 at N = 320 / 640: the 256x320 tile that carries the big-M convolutions of the benchmarked model
+    (16, 64, 64, 320, 0, 320, 3, 1, False),      # M = 65 536: ResnetBlock3D conv at the 64x64 level (B*F = 16)
+    (16, 64, 64, 320, 320, 320, 3, 1, False),    # two-source (skip concat) conv1 of the last up block
+    (16, 64, 64, 320, 0, 320, 1, 1, False),      # 1x1 on the big tile (K = 320: five slabs)
+    (64, 64, 64, 320, 0, 640, 3, 2, False),      # Downsample3D-shaped stride 2: M = 65 536, N = 640
+    (16, 32, 32, 640, 0, 320, 3, 1, True),       # Upsample3D: half-resolution source, M = 65 536
+    (20, 56, 96, 320, 0, 320, 3, 1, False),      # 448x768 frames (56x96 latent): M = 107 520, ragged last M tile
+    (64, 32, 32, 640, 0, 640, 3, 1, False),      # M = 65 536, N = 640 (two column tiles)
 ])
 def test_conv2d(nimg, H, W, C1, C2, Cout, ks, stride, ups):
     x = rnd(nimg, H, W, C1, seed=11)
@@ -127,6 +148,39 @@ def test_conv2d_split_k(nimg, H, W, C1, C2, Cout, stride, ups):
     out = ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec, rows_per_vec=Ho * Wo, residual=res)
     ref = conv_ref(x, w, b, stride, x2, ups) + rowvec.float()[:, None, None, :] + res.float()
     assert rel_err(out, ref) < 2e-3
+
+
+def test_conv2d_big_tile_rowvec_residual():
+    """rowvec (time embedding, one row per batch item) + residual epilogue on the 256x320 tile (M = 65 536)."""
+    nimg, H, W, C, Cout = 16, 64, 64, 320, 320
+    x, w, b = rnd(nimg, H, W, C, seed=71), rnd(Cout, 3, 3, C, seed=72, scale=(9 * C) ** -0.5), rnd(Cout, seed=73)
+    rowvec = rnd(2, Cout, seed=74)
+    res = rnd(nimg, H, W, Cout, seed=75)
+    out = ops().conv2d(x, w, b, rowvec=rowvec, rows_per_vec=8 * H * W, residual=res)
+    ref = conv_ref(x, w, b, 1) + rowvec.float().repeat_interleave(8, 0)[:, None, None, :] + res.float()
+    assert rel_err(out, ref) < 2e-3
+    assert torch.equal(out, ops().conv2d(x, w, b, rowvec=rowvec, rows_per_vec=8 * H * W, residual=res))
+
+
+@pytest.mark.parametrize('M,N,K,res', [(65536, 320, 320, True), (65536, 320, 1280, True), (65536, 960, 320, False),
+                                       (61440, 640, 640, False), (131072, 320, 320, False)])
+def test_linear_big_m(M, N, K, res):
+    """the projections of the 64x64 level at the benchmarked width (256x320 / 128x160 tiles, XCD-remapped grids)"""
+    x, w, b = rnd(M, K, seed=76), rnd(N, K, seed=77, scale=K ** -0.5), rnd(N, seed=78)
+    r = rnd(M, N, seed=79) if res else None
+    out = ops().linear(x, w, b, residual=r)
+    ref = x.float() @ w.float().t() + b.float()
+    if res:
+        ref = ref + r.float()
+    assert rel_err(out, ref) < 2e-3
+
+
+def test_linear_geglu_big_m():
+    M, N, K = 65536, 1280, 320
+    x, w, b = rnd(M, K, seed=80), rnd(2 * N, K, seed=81, scale=K ** -0.5), rnd(2 * N, seed=82)
+    out = ops().linear(x, w, b, geglu=True)
+    y = x.float() @ w.float().t() + b.float()
+    assert rel_err(out, y[:, :N] * F.gelu(y[:, N:])) < 2e-3
 
 
 def test_conv2d_epilogue_rowvec_residual():
@@ -212,7 +266,18 @@ def test_attention_self(nb, heads, nq, nk, d):
     scale = d ** -0.5
     out = ops().attention(q, k, make_vt(v), heads, scale)
     ref, _ = attn_ref(q, k, v, heads, scale)
-    assert rel_err(out, ref) < 4e-3
+    assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
+
+
+def test_attention_self_benchmark_shape():
+    """N = 4096, d = 40, 8 heads: the 64x64-level self-attention of the benchmarked model (32 query tiles per head,
+    XCD-ordered workgroups); nb = 4 keeps the fp32 reference's score tensor at 2 GiB."""
+    nb, heads, nq, d = 4, 8, 4096, 40
+    C = heads * d
+    q, k, v = rnd(nb, nq, C, seed=83), rnd(nb, nq, C, seed=84), rnd(nb, nq, C, seed=85)
+    out = ops().attention(q, k, make_vt(v), heads, d ** -0.5)
+    ref, _ = attn_ref(q, k, v, heads, d ** -0.5)
+    assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 6e-3
 
 
 def test_attention_peaked_softmax():
@@ -225,7 +290,7 @@ def test_attention_peaked_softmax():
     scale = d ** -0.5
     out = ops().attention(q, k, make_vt(v), heads, scale)
     ref, _ = attn_ref(q, k, v, heads, scale)
-    assert rel_err(out, ref) < 4e-3
+    assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
 
 
 @pytest.mark.parametrize('frames,nq,d', [(4, 256, 40), (2, 64, 160), (3, 100, 80)])
@@ -237,7 +302,7 @@ def test_attention_cross_text(frames, nq, d):
     scale = d ** -0.5
     out = ops().attention(q, k, make_vt(v), heads, scale, kv_div=frames)
     ref, _ = attn_ref(q, k, v, heads, scale, kv_div=frames)
-    assert rel_err(out, ref) < 4e-3
+    assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
 
 
 @pytest.mark.parametrize('nb,heads,nq,nk,d,kv_div', [(4, 8, 64, 64, 40, 1), (4, 8, 256, 77, 40, 2), (2, 2, 100, 100, 16, 1)])
@@ -249,15 +314,16 @@ def test_attention_scores_and_pv(nb, heads, nq, nk, d, kv_div):
     probs = ops().attention_scores(q, k, heads, scale, kv_div=kv_div)
     ref_out, ref_p = attn_ref(q, k, v, heads, scale, kv_div=kv_div)
     assert probs.shape == ref_p.shape
-    assert rel_err(probs, ref_p) < 4e-3
+    assert rel_err(probs, ref_p, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
     out = ops().attention_pv(probs, make_vt(v), kv_div=kv_div)
-    assert rel_err(out, ref_out) < 4e-3
+    assert rel_err(out, ref_out, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
     # an edited (non-view) probs tensor must work too
     out2 = ops().attention_pv((probs * 1.0).contiguous(), make_vt(v), kv_div=kv_div)
-    assert rel_err(out2, ref_out) < 4e-3
+    assert rel_err(out2, ref_out, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
 
 
 @pytest.mark.parametrize('B,fq,fk,hw,heads,d', [(2, 16, 16, 64, 8, 40), (1, 4, 4, 256, 8, 80), (2, 16, 16, 16, 8, 160),
+                                               (2, 16, 16, 4096, 8, 40), (1, 8, 8, 1024, 8, 80),
                                                (1, 4, 16, 30, 2, 8), (1, 24, 24, 10, 4, 16)])
 def test_temporal_attention(B, fq, fk, hw, heads, d):
     C = heads * d
@@ -269,7 +335,7 @@ def test_temporal_attention(B, fq, fk, hw, heads, d):
         return t.float().view(B, f, hw, C).permute(0, 2, 1, 3).reshape(B * hw, f, C)
     ref, _ = attn_ref(sites(q, fq), sites(k, fk), sites(v, fk), heads, scale)
     ref = ref.view(B, hw, fq, C).permute(0, 2, 1, 3).reshape(B * fq * hw, C)
-    assert rel_err(out, ref) < 3e-3
+    assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 3e-3
 
 
 # --------------------------------------------------------------------------------------------
@@ -342,7 +408,7 @@ def test_adapter_scatter():
             ref[f, y1, x2] += fc[p] * xf * (1 - yf)
             ref[f, y2, x1] += fc[p] * (1 - xf) * yf
             ref[f, y2, x2] += fc[p] * xf * yf
-    assert rel_err(out.cpu(), ref) < 4e-3
+    assert rel_err(out.cpu(), ref, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
     # on-grid point: a single pixel carries exactly the feature vector
     assert torch.equal(out[2, 3, 2].cpu(), feat[3].cpu()) or rel_err(out[2, 3, 2].cpu(), fc[3]) < 2e-3
 

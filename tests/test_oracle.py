@@ -78,6 +78,33 @@ def test_ddim_inversion_then_sampling_roundtrip():
     assert rel_l2(x, x0) < 2e-2
 
 
+def test_inverse_scheduler_first_step_known_answer():
+    """Hand-computed coefficients of the first inversion step (t = -19 -> 1) of the SD-1.5 scheduler config
+    (scaled_linear 0.00085..0.012, 1000 steps, set_alpha_to_one False): alpha_bar(-19) is `initial_alpha_cumprod`
+    = alphas_cumprod[0] = 1 - 0.00085, NOT 1; alpha_bar(1) = (1 - 0.00085) * (1 - beta_1)."""
+    import math
+    from oracle import diffusers_restated as dr
+    from videoswap_amd import compat
+    b0 = 0.00085
+    b1 = (math.sqrt(0.00085) + (math.sqrt(0.012) - math.sqrt(0.00085)) / 999.0) ** 2
+    want = (1.0 - b0, (1.0 - b0) * (1.0 - b1))
+    for mod in (dr, compat):
+        inv = mod.DDIMInverseScheduler.from_config(mod.DDIMScheduler(**mod.SD15_SCHEDULER_CONFIG).config)
+        inv.set_timesteps(50)
+        assert int(inv.timesteps[0]) == -19
+        assert inv.coefficients(inv.timesteps[0]) == pytest.approx(want, rel=2e-6), mod.__name__
+        one = mod.DDIMInverseScheduler(**{**mod.SD15_SCHEDULER_CONFIG, 'set_alpha_to_one': True})
+        one.set_timesteps(50)
+        assert one.coefficients(-19)[0] == 1.0
+    # the step itself (oracle): x_1 = sqrt(a1) * (x - sqrt(1 - a0) e) / sqrt(a0) + sqrt(1 - a1) e
+    inv = dr.DDIMInverseScheduler(**dr.SD15_SCHEDULER_CONFIG)
+    inv.set_timesteps(50)
+    x, e = torch.full((1, 1), 0.5), torch.full((1, 1), -0.25)
+    a0, a1 = want
+    ref = math.sqrt(a1) * (0.5 - math.sqrt(1 - a0) * -0.25) / math.sqrt(a0) + math.sqrt(1 - a1) * -0.25
+    assert float(inv.step(e, -19, x).prev_sample) == pytest.approx(ref, rel=1e-6)
+
+
 def test_product_schedulers_match_oracle_coefficients():
     from oracle import diffusers_restated as dr
     from videoswap_amd import compat

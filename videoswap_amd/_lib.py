@@ -40,6 +40,7 @@ class GemmDesc(Structure):
 PROTOTYPES = {
     'vsx_abi_version': (c_int, []),
     'vsx_last_error': (c_char_p, []),
+    'vsx_source_digest': (c_char_p, []),
     'vsx_gemm_f16': (c_int, [POINTER(GemmDesc), c_void_p]),
     'vsx_gemm_workspace': (c_int64, [POINTER(GemmDesc)]),
     'vsx_groupnorm_chunks': (c_int64, [c_int64, c_int64]),
@@ -86,6 +87,15 @@ def load():
     ver = lib.vsx_abi_version()
     if ver != VSX_ABI_VERSION:
         raise VsxError(f'libvsx ABI version {ver} != expected {VSX_ABI_VERSION}; rebuild the extension')
+    # a library built from other sources than the ones next to it (a pull that changed csrc/ but left the old
+    # git-ignored .so in place) would silently run stale kernels: refuse it
+    csrc = os.path.join(_HERE, 'csrc')
+    if os.path.isdir(csrc) and not os.environ.get('VSX_SKIP_DIGEST_CHECK'):
+        from .build import source_digest
+        have, want = lib.vsx_source_digest().decode(), source_digest()
+        if have != want:
+            raise VsxError(f'libvsx.so was built from different sources (digest {have[:12]} != {want[:12]}); '
+                           f'rebuild it with `python -m videoswap_amd.build`')
     _lib = lib
     return lib
 

@@ -35,9 +35,28 @@ def _digest():
     return h.hexdigest()
 
 
-def _compile(src):
+def source_digest():
+    """Digest of everything libvsx.so is built from; embedded in the binary (vsx_source_digest)."""
+    return _digest()
+
+
+def built_digest():
+    """Digest embedded in the existing libvsx.so, or None (missing / predates the symbol)."""
+    if not os.path.exists(LIB):
+        return None
+    import ctypes
+    try:
+        fn = ctypes.CDLL(LIB).vsx_source_digest
+    except (OSError, AttributeError):
+        return None
+    fn.restype = ctypes.c_char_p
+    return fn().decode()
+
+
+def _compile(src, digest):
     obj = os.path.join(OBJDIR, src + '.o')
-    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    extra = [f'-DVSX_SOURCE_DIGEST="{digest}"'] if src == 'api.cpp' else []
+    cmd = [HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
@@ -48,22 +67,20 @@ def _compile(src):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, 'libvsx.sha256')
     digest = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+    # the digest lives INSIDE the binary (no side-car stamp file that git could update without the .so)
+    if not force and built_digest() == digest:
         if verbose:
             print(f'[vsx] {LIB} is up to date')
         return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError(f'{HIPCC} not found: cannot build libvsx.so')
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(_compile, SOURCES))
+        objs = list(ex.map(lambda src: _compile(src, digest), SOURCES))
     cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
-    with open(stamp, 'w') as f:
-        f.write(digest)
     if verbose:
         print(f'[vsx] built {LIB}')
     return LIB

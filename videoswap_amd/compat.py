@@ -186,8 +186,9 @@ class DDIMScheduler(_DDIMBase):
 
 
 class DDIMInverseScheduler(_DDIMBase):
-    """Inversion direction, diffusers 0.17-0.19 variant: timesteps -19, 1, 21, ..., 961; each step moves
-    x_t -> x_{t+20}; alpha_bar of the negative first timestep is 1 (clean latents)."""
+    """Inversion direction, diffusers 0.18-0.19 variant: timesteps -19, 1, 21, ..., 961; each step moves
+    x_t -> x_{t+20}; alpha_bar of the negative first timestep is `initial_alpha_cumprod` = 1 when
+    `set_alpha_to_one`, else alphas_cumprod[0] (the SD-1.5 config: 0.99915)."""
 
     def set_timesteps(self, num_inference_steps, device=None):
         self.num_inference_steps = num_inference_steps
@@ -198,5 +199,6 @@ class DDIMInverseScheduler(_DDIMBase):
 
     def coefficients(self, timestep):
         t = int(timestep)
-        a_t = float(self.alphas_cumprod[t]) if t >= 0 else 1.0
+        initial = 1.0 if self.config.set_alpha_to_one else float(self.alphas_cumprod[0])
+        a_t = float(self.alphas_cumprod[t]) if t >= 0 else initial
         return a_t, float(self.alphas_cumprod[t + self._ratio()])

@@ -21,5 +21,12 @@ int vsx_check_launch(const char* what) {
     return VSX_OK;
 }
 
+#ifndef VSX_SOURCE_DIGEST
+#define VSX_SOURCE_DIGEST "unstamped"
+#endif
+
 extern "C" int vsx_abi_version(void) { return VSX_ABI_VERSION; }
+// sha256 of csrc/ + include/vsx.h + the compiler flags this binary was built from (videoswap_amd/build.py): the
+// loader refuses a library whose digest differs from the sources next to it (stale kernels after a pull).
+extern "C" const char* vsx_source_digest(void) { return VSX_SOURCE_DIGEST; }
 extern "C" const char* vsx_last_error(void) { return g_err; }

@@ -335,6 +335,13 @@ def group_norm(x, gamma, beta, groups, eps, nimg, silu=False, x2=None, partial_h
 def layer_norm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0, frame_offset=0):
     _chk(x, 'x'); _chk(gamma, 'gamma'); _chk(beta, 'beta'); _chk(pe, 'pe')
     C = x.shape[-1]
+    if pe is not None:
+        # the kernel indexes pe[(row / rows_per_frame) % frames + frame_offset]: a clip longer than the table
+        # (temporal_position_encoding_max_len) must fail like the reference's shape error, not read past the table
+        if pe.dim() != 2 or pe.shape[1] != C or frames <= 0 or rows_per_frame <= 0 or frame_offset < 0 \
+                or pe.shape[0] < frame_offset + frames:
+            raise _lib.VsxError(f'layer_norm: positional-encoding table {tuple(pe.shape)} does not cover frames '
+                                f'[{frame_offset}, {frame_offset + frames}) x {C} channels')
     y = torch.empty_like(x)
     check(_lib.load().vsx_layernorm(_p(x), x.numel() // C, C, _p(gamma), _p(beta), float(eps), _p(pe), rows_per_frame,
                                     frames, frame_offset, _p(y), _stream()), 'vsx_layernorm')
