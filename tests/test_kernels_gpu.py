@@ -183,6 +183,95 @@ def test_linear_geglu_big_m():
     assert rel_err(out, y[:, :N] * F.gelu(y[:, N:])) < 2e-3
 
 
+# --------------------------------------------------------------------------------------------
+# persistent ping-pong kernel (gemm_pp.hip) against the reference AND bit-for-bit against the workgroup-per-tile
+# kernels (same MFMA, same k order per output element, same epilogue arithmetic)
+# --------------------------------------------------------------------------------------------
+def both_gemm_paths(fn):
+    """fn() under option gemm_pp = 0 (tile kernels only) and 2 (persistent kernel wherever eligible)."""
+    o = ops()
+    try:
+        o.set_option('gemm_pp', 0)
+        a = fn()
+        o.set_option('gemm_pp', 2)
+        b = fn()
+    finally:
+        o.set_option('gemm_pp', 1)
+        o.set_option('pp_sched', 0)
+    return a, b
+
+
+@pytest.mark.parametrize('M,N,K,res,sched', [
+    (65536, 320, 320, True, 0), (65536, 320, 1280, True, 1), (65536, 960, 320, False, 2), (61440, 640, 640, False, 0),
+    (131072, 320, 320, True, 0), (8192, 1280, 1280, True, 0), (8192, 3840, 1280, False, 0), (32768, 640, 2560, True, 0),
+    (65500, 320, 328, True, 0),      # ragged last M tile, K tail (328 = 5 slabs + 8)
+    (5000, 640, 64, False, 0),       # one slab per tile: every stream element changes tile
+    (4096, 640, 640, True, 0),       # 128x320 tiles
+    (2048, 1280, 5120, True, 0),     # 128x320 tiles, long K (split-K on the tile kernels)
+])
+def test_persistent_linear(M, N, K, res, sched):
+    x, w, b = rnd(M, K, seed=90), rnd(N, K, seed=91, scale=K ** -0.5), rnd(N, seed=92)
+    r = rnd(M, N, seed=93) if res else None
+    ops().set_option('pp_sched', sched)
+    old, new = both_gemm_paths(lambda: ops().linear(x, w, b, residual=r))
+    ref = x.float() @ w.float().t() + b.float()
+    if res:
+        ref = ref + r.float()
+    assert rel_err(new, ref) < 2e-3
+    if K < 2560:                     # (split-K on the tile-kernel side sums in a different order)
+        assert torch.equal(old, new), 'persistent and tile kernels must agree bit for bit'
+
+
+@pytest.mark.parametrize('M,N,K', [(65536, 1280, 320), (32768, 2560, 640), (8192, 5120, 1280), (20000, 160, 320)])
+def test_persistent_geglu(M, N, K):
+    x, w, b = rnd(M, K, seed=94), rnd(2 * N, K, seed=95, scale=K ** -0.5), rnd(2 * N, seed=96)
+    old, new = both_gemm_paths(lambda: ops().linear(x, w, b, geglu=True))
+    y = x.float() @ w.float().t() + b.float()
+    assert rel_err(new, y[:, :N] * F.gelu(y[:, N:])) < 2e-3
+    assert torch.equal(old, new)
+
+
+@pytest.mark.parametrize('nimg,H,W,C1,C2,Cout,ks,stride,ups,sched', [
+    (16, 64, 64, 320, 0, 320, 3, 1, False, 0),
+    (16, 64, 64, 320, 320, 320, 3, 1, False, 1),   # two sources
+    (16, 64, 64, 640, 320, 320, 1, 1, False, 0),   # 1x1 shortcut on a concat
+    (64, 64, 64, 320, 0, 640, 3, 2, False, 2),     # stride 2
+    (16, 32, 32, 640, 0, 320, 3, 1, True, 0),      # nearest-2x upsample folded in
+    (20, 56, 96, 320, 0, 320, 3, 1, False, 0),     # ragged M (107 520 rows), Wo = 96
+    (32, 16, 16, 1280, 0, 1280, 3, 1, False, 0),   # M = 8192: 128x320 tiles
+    (3, 28, 48, 128, 64, 640, 3, 1, False, 0),     # M = 4032 (not a multiple of 128), W = 48: 128x320 tiles
+])
+def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched):
+    x = rnd(nimg, H, W, C1, seed=97)
+    x2 = rnd(nimg, H, W, C2, seed=98) if C2 else None
+    Kc = ks * ks * (C1 + C2)
+    w, b = rnd(Cout, ks, ks, C1 + C2, seed=99, scale=Kc ** -0.5), rnd(Cout, seed=100)
+    Ho = (2 * H if ups else H) // stride
+    Wo = (2 * W if ups else W) // stride
+    rowvec, res = rnd(nimg, Cout, seed=101), rnd(nimg, Ho, Wo, Cout, seed=102)
+    ops().set_option('pp_sched', sched)
+    old, new = both_gemm_paths(lambda: ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec,
+                                                    rows_per_vec=Ho * Wo, residual=res))
+    ref = conv_ref(x, w, b, stride, x2, ups) + rowvec.float()[:, None, None, :] + res.float()
+    assert rel_err(new, ref) < 2e-3
+    if nimg * Ho * Wo >= 8192:       # (smaller problems take split-K on the tile-kernel side: other summation order)
+        assert torch.equal(old, new)
+    else:
+        assert rel_err(old, ref) < 2e-3
+
+
+def test_persistent_kernel_is_deterministic_and_repeatable():
+    """Back-to-back launches on one stream reuse the LDS ring and the barrier pattern: 20 launches, identical bits."""
+    x, w, b = rnd(65536, 320, seed=103), rnd(960, 320, seed=104, scale=320 ** -0.5), rnd(960, seed=105)
+    ops().set_option('gemm_pp', 2)
+    try:
+        first = ops().linear(x, w, b)
+        for _ in range(20):
+            assert torch.equal(ops().linear(x, w, b), first)
+    finally:
+        ops().set_option('gemm_pp', 1)
+
+
 def test_conv2d_epilogue_rowvec_residual():
     nimg, H, W, C, Cout = 4, 8, 8, 64, 128
     x, w, b = rnd(nimg, H, W, C, seed=15), rnd(Cout, 3, 3, C, seed=16, scale=(9 * C) ** -0.5), rnd(Cout, seed=17)

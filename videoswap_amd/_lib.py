@@ -41,6 +41,7 @@ PROTOTYPES = {
     'vsx_abi_version': (c_int, []),
     'vsx_last_error': (c_char_p, []),
     'vsx_source_digest': (c_char_p, []),
+    'vsx_set_option': (c_int, [c_char_p, c_int64]),
     'vsx_gemm_f16': (c_int, [POINTER(GemmDesc), c_void_p]),
     'vsx_gemm_workspace': (c_int64, [POINTER(GemmDesc)]),
     'vsx_groupnorm_chunks': (c_int64, [c_int64, c_int64]),

@@ -30,39 +30,18 @@
 // rows interleaved 16+16 inside every 32-row MFMA tile so both halves of a column land in the same lane),
 // transposed store (V^T for the attention kernel).  Accumulators hold C^T (SWAP) so a lane owns one output row and 4
 // consecutive columns per register quad: 8-byte vector loads/stores in the epilogue.
-#include "common.h"
+#include "gemm_common.h"
 #include <cstdlib>
 #include <vector>
 #include <stdlib.h>
+#include <string.h>
+
+using namespace vsxg;
 
 namespace {
 
-constexpr int BK = 64;          // K slab (halfs); LDS rows are 128 B = 8 16-byte slots = one full L2 line per row
+// BK (K slab of 64 halfs: LDS rows are 128 B = one full L2 line per row), GemmParams, lptr_t, wait_vmcnt: gemm_common.h
 // LDS ring depth NSTAGE is a template parameter: 2 slots for the big tiles (57-74 KiB per slab), 4 for the small ones
-
-struct GemmParams {
-    const half_t* A;
-    const half_t* A2;
-    const half_t* B;
-    half_t* C;
-    const half_t* bias;
-    const half_t* rowvec;
-    const half_t* residual;
-    long M, N, K;
-    long lda, ldb, ldc, ldr;
-    long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, r_bs0, r_bs1;
-    long c_rows_per_img, c_img_stride, rows_per_vec;
-    int batch1;
-    int a_mode, H, W, C1, C2, Ho, Wo, ks, stride, ups;
-    int geglu, c_mode, c_pack4, vec4, vec8, rvec8;
-    int tiles_n;
-    unsigned a_bytes, a2_bytes, b_bytes;   // buffer extents (per batch slice) for the SRD bounds check
-    int splitk, nk_per;                    // split-K: grid.z = splitk slices of nk_per slabs, fp32 partials to `ws`
-    float* ws;
-    float alpha;
-};
-
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // -DVSX_GEMM_TIMING (tools/gemm_timing.py builds its own copy of the library): per-wave cycle totals of the main-loop
 // segments, written to the workspace as long[block][wave][4].  Never defined in the product build.
@@ -71,11 +50,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #else
 #define TSTAMP(i) do { } while (0)
 #endif
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // SWAP = true : accumulators hold C^T tiles (MFMA A operand = weight rows, B operand = activation rows), so a lane owns
 //               one output row m and 4 consecutive columns per register quad -> 8-byte epilogue loads/stores.
@@ -886,6 +860,38 @@ static long force_tile() {
     return v;
 }
 
+namespace vsxg {
+namespace {
+struct Option { const char* name; const char* env; long value; bool init; };
+Option g_options[] = {{"gemm_pp", "VSX_GEMM_PP", 1, false}, {"pp_sched", "VSX_PP_SCHED", 0, false}};
+Option* find_option(const char* name) {
+    for (auto& o : g_options)
+        if (strcmp(o.name, name) == 0) {
+            if (!o.init) {
+                const char* e = getenv(o.env);
+                if (e) o.value = atol(e);
+                o.init = true;
+            }
+            return &o;
+        }
+    return nullptr;
+}
+}  // namespace
+long gemm_option(const char* name) {
+    Option* o = find_option(name);
+    return o ? o->value : 0;
+}
+}  // namespace vsxg
+
+extern "C" int vsx_set_option(const char* name, int64_t value) {
+    auto* o = name ? vsxg::find_option(name) : nullptr;
+    if (!o) return vsx_fail(VSX_E_BADSHAPE, "vsx_set_option: unknown option '%s'", name ? name : "(null)");
+    o->value = (long)value;
+    return VSX_OK;
+}
+
+static int pp_mode() { return (int)vsxg::gemm_option("gemm_pp"); }
+
 extern "C" int64_t vsx_gemm_workspace(const vsx_gemm_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
     const long nbatch = d->batch0 * d->batch1;
@@ -1021,7 +1027,16 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     }
     const bool wide = (cols % 320 == 0);
     const int splits = plan_splitk(d, blocks(128, 320), wide && nbatch == 1 && !p.geglu && p.c_mode == 0 && p.vec4);
-    if (force_tile() && wide) {
+    // Persistent ping-pong kernel (gemm_pp.hip): problems with at least ~one 256x320 (or 128x320) tile per CU.
+    // VSX_GEMM_PP=0 disables it (A/B measurements against the workgroup-per-tile kernels), 2 forces it whenever the
+    // shape is eligible.
+    const int pp = pp_mode();
+    const bool pp_ok = pp != 0 && wide && nbatch == 1 && (splits <= 1 || pp == 2) && !force_tile() && pp_supported(p);
+    if (pp_ok && (blocks(256, 320) >= 224 || (pp == 2 && blocks(256, 320) >= 64))) {
+        rc = launch_pp(p, 256, stream);
+    } else if (pp_ok && (blocks(128, 320) >= 224 || (pp == 2 && blocks(128, 320) >= 32))) {
+        rc = launch_pp(p, 128, stream);
+    } else if (force_tile() && wide) {
         p.ws = (float*)d->workspace;
         if (force_tile() == 1) rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);
         else if (force_tile() == 2) rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);

@@ -1,0 +1,52 @@
+// Shared between gemm.hip (workgroup-per-tile kernels) and gemm_pp.hip (persistent ping-pong kernel): the launch
+// parameters and the LDS-DMA helpers.
+#pragma once
+#include "common.h"
+
+namespace vsxg {
+
+constexpr int BK = 64;          // K slab (halfs); LDS rows are 128 B = 8 16-byte slots = one full L2 line per row
+
+struct GemmParams {
+    const half_t* A;
+    const half_t* A2;
+    const half_t* B;
+    half_t* C;
+    const half_t* bias;
+    const half_t* rowvec;
+    const half_t* residual;
+    long M, N, K;
+    long lda, ldb, ldc, ldr;
+    long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, r_bs0, r_bs1;
+    long c_rows_per_img, c_img_stride, rows_per_vec;
+    int batch1;
+    int a_mode, H, W, C1, C2, Ho, Wo, ks, stride, ups;
+    int geglu, c_mode, c_pack4, vec4, vec8, rvec8;
+    int tiles_n;
+    unsigned a_bytes, a2_bytes, b_bytes;   // buffer extents (per batch slice) for the SRD bounds check
+    int splitk, nk_per;                    // split-K: grid.z = splitk slices of nk_per slabs, fp32 partials to `ws`
+    float* ws;
+    float alpha;
+    int tiles_total;                       // persistent kernel: number of output tiles
+};
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#ifdef __HIPCC__
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+#endif  // __HIPCC__
+
+// Tuning / test switches (vsx_set_option; initial values from the environment): "gemm_pp" (VSX_GEMM_PP: 0 = never use
+// the persistent kernel, 1 = where it is expected to win, 2 = wherever the shape is eligible), "pp_sched"
+// (VSX_PP_SCHED: DMA piece schedule variant).
+long gemm_option(const char* name);
+
+// gemm_pp.hip: persistent ping-pong kernel (256x320 / 128x320 tiles).  `bm` selects the row tile.
+bool pp_supported(const GemmParams& p);
+int launch_pp(GemmParams& p, int bm, hipStream_t stream);
+
+}  // namespace vsxg

@@ -417,6 +417,11 @@ def adapter_scatter(tracks, selected, feat, h, w, rate, out_scale=1.0):
     return out
 
 
+def set_option(name, value):
+    """Process-wide tuning / test switch of libvsx (see include/vsx.h: "gemm_pp", "pp_sched")."""
+    check(_lib.load().vsx_set_option(name.encode(), int(value)), 'vsx_set_option')
+
+
 def prof_enable(on, max_samples=4096, stride=1):
     """Bracket every `stride`-th vsx_gemm_f16 launch with hipEvents (bench.py's roofline object)."""
     check(_lib.load().vsx_prof_enable((max(int(stride), 1) if on else 0), max_samples), 'vsx_prof_enable')
