@@ -1,0 +1,113 @@
+"""A/B of the GEMM back ends at the UNet's real shapes: the workgroup-per-tile kernels (option gemm_pp = 0) against the
+persistent ping-pong kernel (gemm_pp = 2) with each of its DMA piece schedules (pp_sched 0/1/2).
+
+    python tools/gemm_ab.py [--batch 2] [--rounds 5] > gpurun_out/gemm_ab.txt
+
+Variants are interleaved round by round inside ONE process (a cross-process comparison has >3 % noise); the table shows
+the median of the per-round times, TFLOP/s of the best variant and the speed-up over the tile kernels.  Shapes: one
+UNet forward at B x 16 frames, 64x64 latent (count = launches per forward)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videoswap_amd import ops  # noqa: E402
+
+DEV, H16 = 'cuda', torch.float16
+
+
+def r(*s, scale=1.0):
+    return (torch.randn(*s, device=DEV, dtype=torch.float32) * scale).to(H16)
+
+
+def shapes(B):
+    BF = 16 * B
+    out = []
+    lv = [(64, 320), (32, 640), (16, 1280), (8, 1280)]
+    for hw, c in lv:
+        M = BF * hw * hw
+        n_blk = {64: 5, 32: 5, 16: 5, 8: 0}[hw]          # transformer blocks at this level (spatial == temporal count)
+        if n_blk:
+            out.append(('plain', f'proj {c}->{c} +res', dict(M=M, N=c, K=c, res=True), 9 * n_blk))
+            out.append(('plain', f'qkv {c}->{3 * c}', dict(M=M, N=3 * c, K=c, res=False), 2 * n_blk))
+            out.append(('plain', f'qk {c}->{2 * c}', dict(M=M, N=2 * c, K=c, res=False), n_blk))
+            out.append(('geglu', f'geglu {c}->{4 * c}', dict(M=M, N=4 * c, K=c), 2 * n_blk))
+            out.append(('plain', f'ff2 {4 * c}->{c} +res', dict(M=M, N=c, K=4 * c, res=True), 2 * n_blk))
+    convs = [(64, 320, 0, 320, 1, False, 7), (64, 320, 320, 320, 1, False, 2), (64, 640, 320, 320, 1, False, 1),
+             (64, 320, 0, 320, 2, False, 1), (32, 640, 0, 640, 1, False, 6), (32, 640, 640, 640, 1, False, 1),
+             (32, 320, 0, 640, 1, False, 1), (32, 1280, 640, 640, 1, False, 1), (32, 640, 0, 640, 1, True, 1),
+             (16, 1280, 0, 1280, 1, False, 6), (16, 1280, 1280, 1280, 1, False, 2), (16, 640, 0, 1280, 1, False, 1),
+             (16, 1280, 0, 1280, 1, True, 1), (8, 1280, 0, 1280, 1, False, 11), (8, 1280, 1280, 1280, 1, False, 3)]
+    for hw, c1, c2, co, st, up, n in convs:
+        out.append(('conv', f'conv3x3 {hw}x{hw} {c1}+{c2}->{co}' + ('/s2' if st == 2 else '') + (' up' if up else ''),
+                    dict(nimg=BF, hw=hw, c1=c1, c2=c2, co=co, stride=st, up=up), n))
+    return out
+
+
+def make(kind, a):
+    if kind in ('plain', 'geglu'):
+        M, N, K = a['M'], a['N'], a['K']
+        x = r(M, K)
+        if kind == 'geglu':
+            w, b = r(2 * N, K, scale=K ** -0.5), r(2 * N)
+            return (lambda: ops.linear(x, w, b, geglu=True)), 2.0 * M * 2 * N * K
+        w, b = r(N, K, scale=K ** -0.5), r(N)
+        res = r(M, N) if a['res'] else None
+        return (lambda: ops.linear(x, w, b, residual=res)), 2.0 * M * N * K
+    hw = a['hw'] // 2 if a['up'] else a['hw']
+    x = r(a['nimg'], hw, hw, a['c1'])
+    x2 = r(a['nimg'], hw, hw, a['c2']) if a['c2'] else None
+    cin = a['c1'] + a['c2']
+    w, b = r(a['co'], 3, 3, cin, scale=(9 * cin) ** -0.5), r(a['co'])
+    ho = a['hw'] // a['stride']
+    rv = r(a['nimg'] // 16, a['co'])
+    return (lambda: ops.conv2d(x, w, b, x2=x2, stride=a['stride'], upsample=a['up'], rowvec=rv,
+                               rows_per_vec=16 * ho * ho)), 2.0 * a['nimg'] * ho * ho * a['co'] * 9 * cin
+
+
+def time_once(fn, reps):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--reps', type=int, default=4)
+    args = ap.parse_args()
+    variants = [('tile', 0, 0), ('pp/s0', 2, 0), ('pp/s1', 2, 1), ('pp/s2', 2, 2)]
+    print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
+    print(f'{"shape":44s} {"n":>3s} ' + ' '.join(f'{v[0]:>8s}' for v in variants) + '   best TF/s  speedup  fwd-ms tile -> best')
+    tot_old = tot_best = 0.0
+    for kind, name, a, count in shapes(args.batch):
+        fn, flop = make(kind, a)
+        ts = {v[0]: [] for v in variants}
+        for v in variants:                      # warm every variant (first launch sets the LDS attribute)
+            ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2])
+            fn()
+        torch.cuda.synchronize()
+        for _ in range(args.rounds):
+            for v in variants:
+                ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2])
+                ts[v[0]].append(time_once(fn, args.reps))
+        med = {k: sorted(x)[len(x) // 2] * 1000.0 for k, x in ts.items()}
+        best = min(med, key=med.get)
+        tot_old += med['tile'] * count / 1000.0
+        tot_best += med[best] * count / 1000.0
+        print(f'{name:44s} {count:3d} ' + ' '.join(f'{med[v[0]]:8.1f}' for v in variants) +
+              f'   {flop / med[best] / 1e6:7.1f}  {med["tile"] / med[best]:6.2f}x  {best:6s}'
+              f' {med["tile"] * count / 1000:6.2f} -> {med[best] * count / 1000:6.2f}', flush=True)
+    ops.set_option('gemm_pp', 1); ops.set_option('pp_sched', 0)
+    print(f'# GEMM time per forward (listed shapes): tile kernels {tot_old:.2f} ms, best-of {tot_best:.2f} ms')
+
+
+if __name__ == '__main__':
+    main()

@@ -96,7 +96,7 @@ def load():
         have, want = lib.vsx_source_digest().decode(), source_digest()
         if have != want:
             raise VsxError(f'libvsx.so was built from different sources (digest {have[:12]} != {want[:12]}); '
-                           f'rebuild it with `python -m videoswap_amd.build`')
+                           f'rebuild it with `python -m videoswap_amd.build` (VSX_SKIP_DIGEST_CHECK=1 overrides)')
     _lib = lib
     return lib
 

@@ -27,11 +27,14 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
 
 
 def _digest():
+    """sha256 over the kernel sources, the public header and the compiler flags.  Location-independent: the flags
+    are hashed with the checkout path stripped (the gpurun snapshot lives under another root than the build tree)."""
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)) + ['../../include/vsx.h']:
+    names = [n for n in sorted(os.listdir(CSRC)) if n.endswith(('.hip', '.cpp', '.h'))]
+    for name in names + ['../../include/vsx.h']:
         with open(os.path.join(CSRC, name), 'rb') as f:
             h.update(name.encode() + b'\0' + f.read())
-    h.update(' '.join(FLAGS).encode())
+    h.update(' '.join(f.replace(ROOT, '<root>') for f in FLAGS).encode())
     return h.hexdigest()
 
 
