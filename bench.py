@@ -44,6 +44,9 @@ def parse():
     # hipEvent pairs around every 7th vsx_gemm_f16 launch (7 is coprime with the ~470 GEMM launches of a UNet call, so
     # every shape is sampled over the 100 calls of a clip); bracketing EVERY launch costs 5 % of the loop
     ap.add_argument('--prof-stride', type=int, default=7)
+    ap.add_argument('--no-graphs', action='store_true',
+                    help='launch every kernel eagerly (default: HIP-graph replay of the UNet forward; every '
+                         '--prof-stride-th UNet call stays eager and carries the hipEvent brackets)')
     return ap.parse_args()
 
 
@@ -73,11 +76,14 @@ def one_clip(pipe, data, ddim_steps):
     return out
 
 
-def cpu_baseline(frames_sample=2, latent=64):
-    """The oracle (CPU port of the reference's PyTorch path, fp32) on the host cores: one UNet forward (B=1) on a
-    bounded sample of `frames_sample` frames at the full SD-1.5 width and the same 64x64 latent."""
+def cpu_baseline(frames_sample=2, latent=64, repeats=2):
+    """The oracle (CPU port of the reference's PyTorch path, fp32) on the host cores: one inversion-step UNet forward
+    (B=1) on a bounded sample of `frames_sample` frames at the full SD-1.5 width and the same 64x64 latent; one
+    warm-up forward, then the median of `repeats` timed forwards (with the sample bounded to ~30 s of
+    CPU work as the bench contract asks: a full T=16 step pair is ~5 min on 128 cores)."""
     from oracle import unet3d
     torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
     threads = torch.get_num_threads()
     model = unet3d.AnimateDiffUNet3DModel(**unet3d.full_config()).eval()
     for n, p in model.named_parameters():           # proj_out is zero-initialised: make the temporal path live
@@ -85,12 +91,31 @@ def cpu_baseline(frames_sample=2, latent=64):
             torch.nn.init.normal_(p, std=0.02)
     x = torch.randn(1, 4, frames_sample, latent, latent)
     txt = torch.randn(1, 77, 768)
+    times = []
     with torch.no_grad():
-        t0 = time.time()
-        model(x, torch.tensor(481), txt)
-        dt = time.time() - t0
+        model(x, torch.tensor(481), txt)            # warm-up (allocator, thread pool, oneDNN primitive caches)
+        for _ in range(repeats):
+            t0 = time.time()
+            model(x, torch.tensor(481), txt)
+            times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
     evals_per_s = frames_sample / dt
-    return evals_per_s, threads, f'1 UNet forward, B=1, T={frames_sample}, {latent}x{latent} latent, fp32, {dt:.1f} s'
+    return evals_per_s, threads, (f'1 UNet forward (inversion step), B=1, T={frames_sample}, {latent}x{latent} latent, '
+                                  f'fp32, 1 warm-up + median of {repeats}: {dt:.1f} s')
+
+
+def gemm_traffic(frames, latent):
+    """HBM bytes per vsx_gemm_f16 launch from the PMC passes of tools/pmc_traffic.sh — only if that file was measured
+    on THIS build of the library (source digest) at the benchmark shape; a stale file is not a measurement."""
+    from videoswap_amd.build import source_digest
+    path = os.path.join(ROOT, 'profiles', 'r02_gemm_hbm_traffic.json')
+    if not os.path.exists(path) or frames != 16 or latent != 64:
+        return None, 'no PMC traffic file for this shape'
+    with open(path) as f:
+        t = json.load(f)
+    if t.get('lib_digest') != source_digest():
+        return None, f'PMC traffic file is from another build ({str(t.get("lib_digest"))[:12]})'
+    return round(t['hbm_bytes_per_launch']), f'{t["launches"]} launches of one inversion + one CFG step'
 
 
 def main():
@@ -120,18 +145,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    graphs = not args.no_graphs
+    if graphs:
+        # graph replay for the UNet forward; every prof_stride-th call runs eagerly and is the one whose GEMM launches
+        # are bracketed by hipEvents (ALL of them: same 1/stride sampling fraction as the eager mode's every-7th-launch)
+        pipe.unet.enable_hip_graphs(True, eager_every=args.prof_stride if args.prof_samples > 0 else 0)
+        if args.warmup == 0:
+            one_clip(pipe, clips[0], 1)              # capture the two graphs (B=1, B=2) outside the timed region
     for i in range(args.warmup):
         one_clip(pipe, clips[i % len(clips)], args.ddim_steps)
     barrier()
+    if graphs:
+        pipe.unet._graphs.on_eager = (lambda on: ops.prof_pause(not on))
 
     ops.FlopCounter.reset(True)
-    ops.prof_enable(args.prof_samples > 0, args.prof_samples, stride=args.prof_stride)
+    ops.prof_enable(args.prof_samples > 0, args.prof_samples, stride=1 if graphs else args.prof_stride)
+    if graphs:
+        ops.prof_pause(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_clip(pipe, clips[i % len(clips)], args.ddim_steps)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.FlopCounter.enabled = False
+    ops.prof_pause(False)
     n_launch, gemm_ms, gemm_flop = ops.prof_collect()
     ops.prof_enable(False, 0)
 
@@ -147,7 +184,7 @@ def main():
         'value': round(value, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 2), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-        'config': {'workload': f'{args.frames}-frame {args.latent * 8}x{args.latent * 8} clip, SD-1.5 UNet3D + '
+        'config': {'launch': 'hip-graph' if graphs else 'eager', 'workload': f'{args.frames}-frame {args.latent * 8}x{args.latent * 8} clip, SD-1.5 UNet3D + '
                                f'AnimateDiff motion modules, {args.ddim_steps}-step DDIM inversion (B=1) + '
                                f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B=2), one clip per GPU per step',
                    'latents': [1, 4, args.frames, args.latent, args.latent], 'parallelism': f'clip-parallel x{world}'},
@@ -160,15 +197,14 @@ def main():
     }
     if n_launch > 0 and gemm_ms > 0:
         ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh (same launch mix)
-        tpath = os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')
-        if os.path.exists(tpath) and args.frames == 16 and args.latent == 64:
-            with open(tpath) as f:
-                traffic = round(json.load(f)['hbm_bytes_per_launch'])
+        traffic, traffic_note = gemm_traffic(args.frames, args.latent)
         out['roofline'] = {'bound': 'mfma', 'kernel': 'vsx_gemm_f16 (implicit-GEMM conv + GEMM, all shapes)',
                            'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                           'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_note,
                            'launches_sampled': int(n_launch), 'sample_stride': args.prof_stride,
+                           'sampling': ('all GEMM launches of every %d-th UNet call (eager); the other calls are '
+                                        'HIP-graph replays' % args.prof_stride) if graphs else
+                                       ('every %d-th GEMM launch' % args.prof_stride),
                            'avg_launch_us': round(1000.0 * gemm_ms / n_launch, 2),
                            'avg_launch_gflop': round(gemm_flop / n_launch / 1e9, 2),
                            'kernel_time_share_of_wall': round(gemm_ms * 1e-3 * args.prof_stride / (elapsed * 1.0), 4)}

@@ -209,6 +209,8 @@ int vsx_adapter_scatter(const float* tracks, const int32_t* selected, const void
  * summed duration (ms) and summed algorithmic FLOP (2*M*N*K*batch; geglu counts B's 2N rows).
  * ------------------------------------------------------------------------------------------ */
 int vsx_prof_enable(int64_t on, int64_t max_samples);
+/* suspend (1) / resume (0) the sampling: events cannot be recorded while a stream is being captured into a HIP graph */
+int vsx_prof_pause(int64_t paused);
 int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* total_flop);
 
 #ifdef __cplusplus

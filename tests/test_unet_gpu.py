@@ -115,3 +115,64 @@ def test_step_invariant_caches_follow_inputs_and_weights(setup):
     assert torch.equal(c, d), 'a weight reload must invalidate the cached projections'
     assert not torch.equal(c, cold)
     assert torch.equal(e, cold)
+
+
+def test_hip_graph_replay_is_bit_identical_to_eager(setup):
+    """The captured forward replays the same kernels on the same data layout: bit-identical outputs, across
+    timesteps, texts, adapter residuals and a weight reload (which must drop the graph)."""
+    blob, ora, prod = setup
+    case = blob['cases']['cfg_adapter_T3_16x24']
+    x, txt = case['sample'].half().cuda(), case['text'].half().cuda()
+    res = [r.half().cuda() for r in case['residuals']]
+    with torch.no_grad():
+        eager = [prod(x, t, txt).sample for t in (21, 481)]
+        eager_res = prod(x, 21, txt, down_block_additional_residuals=list(res)).sample
+        prod.enable_hip_graphs(True)
+        try:
+            for _ in range(2):                       # second round: pure replays
+                for t, ref in zip((21, 481), eager):
+                    assert torch.equal(prod(x, t, txt).sample, ref)
+            lst = list(res)
+            assert torch.equal(prod(x, 21, txt, down_block_additional_residuals=lst).sample, eager_res)
+            assert lst == []
+            assert prod._graphs.captures == 2 and prod._graphs.replays >= 5
+            other = (txt * 0.5).contiguous()
+            ref_other = prod(x, 21, other).sample     # same shapes: same graph, new text copied in
+            prod.enable_hip_graphs(False)
+            assert torch.equal(prod(x, 21, other).sample, ref_other)
+            prod.enable_hip_graphs(True)
+            sd = {k: v.clone() for k, v in prod.state_dict().items()}
+            name = next(k for k in sd if k.endswith('attn1.to_q.weight'))
+            sd2 = dict(sd)
+            sd2[name] = sd[name] * 1.25
+            prod(x, 21, txt)
+            prod.load_state_dict(sd2)
+            changed = prod(x, 21, txt).sample
+            assert not torch.equal(changed, eager[0])
+            prod.load_state_dict(sd)
+            assert torch.equal(prod(x, 21, txt).sample, eager[0])
+        finally:
+            prod.enable_hip_graphs(False)
+
+
+def test_hip_graphs_step_aside_for_controllers(setup):
+    """Prompt-to-Prompt control processors keep host state per call: the graph path must not be taken."""
+    from videoswap_amd import control
+    blob, ora, prod = setup
+    case = blob['cases']['plain_T4_16x16']
+    x, txt = case['sample'].half().cuda(), case['text'].half().cuda()
+    pipe = type('P', (), {'unet': prod})()
+    with torch.no_grad():
+        prod.enable_hip_graphs(True)
+        try:
+            store = control.AttentionStore()
+            control.register_attention_control(pipe, store)
+            prod(x, 481, txt)
+            assert prod._graphs.captures == 0 and prod._graphs.replays == 0
+            control.register_attention_control(pipe, control.EmptyControl())
+        finally:
+            prod.enable_hip_graphs(False)
+            from videoswap_amd.attention import AttnProcessor2_0
+            for name, m in prod.named_modules():
+                if m.__class__.__name__ == 'Attention' and ('attn1' in name or 'attn2' in name):
+                    m.set_processor(AttnProcessor2_0())

@@ -65,6 +65,7 @@ PROTOTYPES = {
     'vsx_adapter_scatter': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_int64, c_float, c_float, c_void_p]),
     'vsx_prof_enable': (c_int, [c_int64, c_int64]),
+    'vsx_prof_pause': (c_int, [c_int64]),
     'vsx_prof_collect': (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
 }
 

@@ -65,7 +65,10 @@ class Attention(nn.Module):
             cache[names] = hit
         return hit[1]
 
+    processor_epoch = 0     # bumped by every set_processor (HIP-graph caches key on it)
+
     def set_processor(self, processor):
+        Attention.processor_epoch += 1
         if (hasattr(self, 'processor') and isinstance(self.processor, nn.Module)
                 and not isinstance(processor, nn.Module)):
             self._modules.pop('processor')
@@ -143,6 +146,7 @@ def _project_kv(attn, hidden_states, encoder_hidden_states, layer_idx=None):
 class _FusedProcessor:
     """Fused flash attention (never materialises the probabilities)."""
     vsx_native = True
+    vsx_graph_safe = True       # launches only: may run inside a HIP-graph capture
 
     def __init__(self, cross_attention_idx=None):
         self.cross_attention_idx = cross_attention_idx
@@ -258,6 +262,10 @@ class VanillaAttentionProcessor(nn.Module):
     K/V rows of the other ranks' frames over RCCL before the attention.
     """
     vsx_native = True
+
+    @property
+    def vsx_graph_safe(self):
+        return self.kv_gather is None
 
     def __init__(self, attention_mode=None, cross_frame_attention_mode=None, temporal_position_encoding=False,
                  temporal_position_encoding_max_len=24, attention_op=None, *args, **kwargs):

@@ -808,6 +808,7 @@ int launch_tile(GemmParams& p, long M, long cols, long nbatch, hipStream_t strea
 // ---- instrumentation (bench.py roofline): hipEvent pairs around sampled launches ----
 struct ProfState {
     bool on = false;
+    bool paused = false;
     long max_samples = 0;
     long stride = 1, seen = 0;
     long n = 0;
@@ -827,6 +828,12 @@ extern "C" int vsx_prof_enable(int64_t on, int64_t max_samples) {
     g_prof.max_samples = max_samples;
     g_prof.n = 0;
     g_prof.flop = 0.0;
+    return VSX_OK;
+}
+
+// suspend / resume sampling without touching what has been collected (HIP-graph capture and replayed calls)
+extern "C" int vsx_prof_pause(int64_t paused) {
+    g_prof.paused = paused != 0;
     return VSX_OK;
 }
 
@@ -1012,7 +1019,8 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     auto blocks = [&](long bm, long bn) { return ((d->M + bm - 1) / bm) * ((cols + bn - 1) / bn) * nbatch; };
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool sample = g_prof.on && g_prof.n < g_prof.max_samples && (g_prof.seen++ % g_prof.stride) == 0;
+    const bool sample = g_prof.on && !g_prof.paused && g_prof.n < g_prof.max_samples &&
+                        (g_prof.seen++ % g_prof.stride) == 0;
     if (sample) {
         if ((long)g_prof.ev->size() < 2 * (g_prof.n + 1)) {
             hipEvent_t a, b;

@@ -422,8 +422,21 @@ def set_option(name, value):
     check(_lib.load().vsx_set_option(name.encode(), int(value)), 'vsx_set_option')
 
 
+_prof_state = {'on': 0, 'max': 0, 'stride': 1, 'paused': False}
+
+
+def prof_pause(paused):
+    """Suspend / resume the hipEvent bracketing of GEMM launches (graph capture and graph-replayed calls)."""
+    if paused == _prof_state['paused']:
+        return
+    _prof_state['paused'] = paused
+    if _prof_state['on']:
+        check(_lib.load().vsx_prof_pause(1 if paused else 0), 'vsx_prof_pause')
+
+
 def prof_enable(on, max_samples=4096, stride=1):
     """Bracket every `stride`-th vsx_gemm_f16 launch with hipEvents (bench.py's roofline object)."""
+    _prof_state.update(on=1 if on else 0, max=max_samples, stride=stride, paused=False)
     check(_lib.load().vsx_prof_enable((max(int(stride), 1) if on else 0), max_samples), 'vsx_prof_enable')
 
 

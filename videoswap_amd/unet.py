@@ -573,6 +573,8 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         self._frame_shard = None      # videoswap_amd.distributed.FrameShard for the long-clip mode
         self._temb_cache = {}
         self._semb_cache = {}
+        self._graphs = None           # graphs.GraphCache when HIP-graph replay is enabled
+        self._weights_epoch = getattr(self, '_weights_epoch', 0)
 
     # ---------------------------------------------------------------------------------------------
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
@@ -588,9 +590,6 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         up = 2 ** self.num_upsamplers
         if H % up or W % up:
             raise NotImplementedError(f'latent sides must be multiples of {up} (got {H}x{W})')
-        shard = self._frame_shard
-        geo = Geometry(B, F, None if shard is None else shard.gn_hook, None if shard is None else shard.total_frames)
-
         # time embedding (unet.py:376-397)
         timesteps = timestep
         if not torch.is_tensor(timesteps):
@@ -599,17 +598,35 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
             timesteps = timesteps[None]
         silu_emb = self._silu_time_embedding(timesteps, B, sample.device)
 
+        residuals = down_block_additional_residuals
+        if residuals is not None:
+            # the caller's list is consumed (unet.py:422,435); layout conversion happens outside the captured body
+            taken = [residuals.pop(0) for _ in range(len(residuals))]
+            residuals = [r if getattr(r, 'vsx_nhwc', False) else r.permute(0, 2, 3, 1).contiguous() for r in taken]
+        if self._graphs is not None and self._graphable(sample, silu_emb, encoder_hidden_states):
+            out = self._graphs.run(self, sample, silu_emb, encoder_hidden_states, residuals)
+        else:
+            out = self._forward_body(sample, silu_emb, encoder_hidden_states, residuals)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    def _forward_body(self, sample, silu_emb, encoder_hidden_states, residuals):
+        """Everything between the time embedding and the output tensor: kernel launches on the current stream and
+        device allocations only (no host synchronisation, no host-side data dependence), so that it can be captured
+        into a HIP graph (`enable_hip_graphs`).  `residuals`: channels-last adapter maps or None."""
+        B, _, F, H, W = sample.shape
+        shard = self._frame_shard
+        geo = Geometry(B, F, None if shard is None else shard.gn_hook, None if shard is None else shard.total_frames)
+
         x = ops.pack_latents(sample.contiguous(), 8)            # [B*F, H, W, 8] (latent channels zero-padded)
         x = self.conv_in(x)
 
-        residuals = down_block_additional_residuals
         is_adapter = residuals is not None
+        residuals = list(residuals) if is_adapter else None
 
         def pop_residual():
-            r = residuals.pop(0)
-            if not getattr(r, 'vsx_nhwc', False):
-                r = r.permute(0, 2, 3, 1).contiguous()
-            return r
+            return residuals.pop(0)
 
         skips = (x,)
         for blk in self.down_blocks:
@@ -633,10 +650,40 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         rows = None if geo.gn_frames is None else geo.gn_frames * H * W
         x = self.conv_norm_out(x, B, silu=True, partial_hook=geo.gn_hook, count_rows=rows)
         x = self.conv_out(x)
-        out = ops.unpack_latents(x, B, self.config.out_channels)
-        if not return_dict:
-            return (out,)
-        return UNet3DConditionOutput(sample=out)
+        return ops.unpack_latents(x, B, self.config.out_channels)
+
+    # ---------------------------------------------------------------------------------------------
+    def enable_hip_graphs(self, enabled=True, eager_every=0):
+        """Replay the forward as a captured HIP graph (one per input signature) instead of ~700 eager launches: the
+        launch-bound 16x16 / 8x8 levels leave the GPU idle between kernels in eager mode (profiles/r01_kernel_stats_v7:
+        8.3 % of the span).  `eager_every = k > 0` runs every k-th call eagerly (bench.py brackets the GEMM launches of
+        those calls with hipEvents: events cannot bracket the kernels of a graph replay).  Graphs are dropped when the
+        weights or the attention processors change (load_state_dict / .to() / set_processor); call
+        `invalidate_graphs()` after editing parameters in place."""
+        from .graphs import GraphCache
+        self._graphs = GraphCache(eager_every) if enabled else None
+
+    def invalidate_graphs(self):
+        self._weights_epoch += 1
+
+    def load_state_dict(self, *args, **kwargs):
+        self._weights_epoch += 1
+        return super().load_state_dict(*args, **kwargs)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._weights_epoch = getattr(self, '_weights_epoch', 0) + 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def _graphable(self, sample, silu_emb, text):
+        if self._frame_shard is not None or not sample.is_cuda or silu_emb.shape[0] != 1:
+            return False
+        from .attention import Attention
+        if self.__dict__.get('_native_epoch') != Attention.processor_epoch:
+            # every processor must be a fused native one: controllers keep host-side state per call
+            self.__dict__['_all_native'] = all(
+                getattr(m.processor, 'vsx_graph_safe', False) for m in self.modules() if isinstance(m, Attention))
+            self.__dict__['_native_epoch'] = Attention.processor_epoch
+        return self.__dict__['_all_native']
 
     def _silu_time_embedding(self, timesteps, B, device):
         """SiLU(time_embedding(time_proj(t))) (unet.py:376-397; every consumer applies SiLU first, resnet.py:172).
@@ -663,6 +710,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         text K/V per cross-attention layer).  They are keyed on parameter versions, so this is never needed for
         correctness; bench.py calls it at the start of every timed clip so that no clip profits from the previous."""
         self._semb_cache.clear()
+        self._temb_cache.clear()
         for m in self.modules():
             m.__dict__.pop('_tproj', None)
             m.__dict__.pop('_text_kv', None)
