@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 3
+#define VSX_ABI_VERSION 4
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -100,6 +100,10 @@ typedef struct vsx_gemm_desc {
        / long-K problems (the 8x8 and 16x16 UNet levels) are then sliced along K so that every CU gets a tile. */
     void* workspace;
     int64_t workspace_bytes;
+    /* ABI v4, a_mode 1: zero padding before (top / left) and after (bottom / right) the image, 0..ks-1 each; the
+       pair (-1, -1) selects the symmetric ks/2 of nn.Conv2d(padding=ks//2).  diffusers' VAE encoder downsamples with
+       F.pad(x, (0, 1, 0, 1)) + a stride-2 conv without padding = (pad_lo, pad_hi) = (0, 1). */
+    int64_t pad_lo, pad_hi;
 } vsx_gemm_desc;
 
 int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream);

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so')
 
-VSX_ABI_VERSION = 3
+VSX_ABI_VERSION = 4
 
 
 class VsxError(RuntimeError):
@@ -18,7 +18,15 @@ class VsxError(RuntimeError):
 
 
 class GemmDesc(Structure):
-    """Mirror of ``struct vsx_gemm_desc`` (every field is 8 bytes)."""
+    """Mirror of ``struct vsx_gemm_desc`` (every field is 8 bytes).  pad_lo / pad_hi default to -1 (symmetric ks/2)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if 'pad_lo' not in kwargs:
+            self.pad_lo = -1
+        if 'pad_hi' not in kwargs:
+            self.pad_hi = -1
+
     _fields_ = [
         ('M', c_int64), ('N', c_int64), ('K', c_int64),
         ('batch0', c_int64), ('batch1', c_int64),
@@ -33,6 +41,7 @@ class GemmDesc(Structure):
         ('residual', c_void_p), ('ldr', c_int64), ('r_bs0', c_int64), ('r_bs1', c_int64),
         ('geglu', c_int64), ('alpha', c_double),
         ('workspace', c_void_p), ('workspace_bytes', c_int64),
+        ('pad_lo', c_int64), ('pad_hi', c_int64),
     ]
 
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     int va[GA];                                   // current voffset of each A row (plain: fixed; conv: per tap)
     const int Hs = p.ups ? (p.H >> 1) : p.H;
     const int Ws = p.ups ? (p.W >> 1) : p.W;
-    const int pad = p.ks >> 1;
+    const int pad = p.pad;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
         const long m = m0 + (wave * GA + i) * 8 + lrow;
@@ -979,9 +979,13 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
         VSX_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), VSX_E_BADSHAPE, "gemm: upsample needs even H/W");
         p.H = (int)d->H; p.W = (int)d->W; p.C1 = (int)d->C1; p.C2 = (int)d->C2;
         p.ks = (int)d->ks; p.stride = (int)d->stride; p.ups = d->upsample ? 1 : 0;
-        const int pad = p.ks / 2;
-        p.Ho = (p.H + 2 * pad - p.ks) / p.stride + 1;
-        p.Wo = (p.W + 2 * pad - p.ks) / p.stride + 1;
+        const bool sym = d->pad_lo < 0 && d->pad_hi < 0;
+        VSX_REQUIRE(sym || (d->pad_lo >= 0 && d->pad_hi >= 0 && d->pad_lo < d->ks && d->pad_hi < d->ks), VSX_E_BADSHAPE,
+                    "gemm: conv padding (%ld, %ld) for kernel size %ld", (long)d->pad_lo, (long)d->pad_hi, (long)d->ks);
+        const int pad_lo = sym ? p.ks / 2 : (int)d->pad_lo, pad_hi = sym ? p.ks / 2 : (int)d->pad_hi;
+        p.pad = pad_lo;
+        p.Ho = (p.H + pad_lo + pad_hi - p.ks) / p.stride + 1;
+        p.Wo = (p.W + pad_lo + pad_hi - p.ks) / p.stride + 1;
         {
             const long pix = (d->M / ((long)p.Ho * p.Wo)) * (long)(p.ups ? p.H / 2 : p.H) * (p.ups ? p.W / 2 : p.W);
             VSX_REQUIRE(pix * d->C1 * 2 < (1L << 31) && pix * d->C2 * 2 < (1L << 31), VSX_E_UNSUPPORTED,

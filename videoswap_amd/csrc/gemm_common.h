@@ -20,7 +20,7 @@ struct GemmParams {
     long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, r_bs0, r_bs1;
     long c_rows_per_img, c_img_stride, rows_per_vec;
     int batch1;
-    int a_mode, H, W, C1, C2, Ho, Wo, ks, stride, ups;
+    int a_mode, H, W, C1, C2, Ho, Wo, ks, stride, ups, pad;     // pad: zero rows / columns before the image
     int geglu, c_mode, c_pack4, vec4, vec8, rvec8;
     int tiles_n;
     unsigned a_bytes, a2_bytes, b_bytes;   // buffer extents (per batch slice) for the SRD bounds check

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         i_rowB = (unsigned)(geglu ? tile_n * (BN / 2) : tile_n * BN) * ldb2;
         if constexpr (CONV) {
             const unsigned Wo = (unsigned)p->Wo, hw = (unsigned)p->Ho * Wo;
-            const int stride = p->stride, pad = p->ks >> 1;
+            const int stride = p->stride, pad = p->pad;
             const int Hs = p->ups ? (p->H >> 1) : p->H;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {

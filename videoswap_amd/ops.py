@@ -140,13 +140,14 @@ def linear_vt(x, weight, bias, rows_per_img, ldvt=None):
 
 
 def conv2d(x, weight, bias=None, *, x2=None, stride=1, upsample=False, rowvec=None, rows_per_vec=0,
-           residual=None):
+           residual=None, padding=None):
     """Channels-last conv as implicit GEMM.
 
     x [nimg, H, W, C1] (+ x2 [nimg, H, W, C2] concatenated on C); weight [Cout, ks, ks, C1+C2] contiguous
     (== a channels_last-format nn.Conv2d weight); returns [nimg, Ho, Wo, Cout].  `upsample`: x/x2 are at half
     resolution and are read as their nearest-2x upsampling.  rowvec [nvec, Cout] is added to rows
     [i*rows_per_vec, (i+1)*rows_per_vec) (time embedding); residual [nimg, Ho, Wo, Cout] is added last.
+    `padding` = (before, after) zero rows/columns (default ks//2 each); (0, 1) is diffusers' Downsample2D(padding=0).
     """
     _chk(x, 'x'); _chk(x2, 'x2'); _chk(weight, 'weight'); _chk(bias, 'bias'); _chk(rowvec, 'rowvec')
     _chk(residual, 'residual')
@@ -156,11 +157,13 @@ def conv2d(x, weight, bias=None, *, x2=None, stride=1, upsample=False, rowvec=No
     if weight.shape[2] != ks or weight.shape[3] != C1 + C2:
         raise _lib.VsxError(f'conv2d: weight {tuple(weight.shape)} does not match input channels {C1}+{C2}')
     H, W = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
-    pad = ks // 2
-    Ho = (H + 2 * pad - ks) // stride + 1
-    Wo = (W + 2 * pad - ks) // stride + 1
+    pad_lo, pad_hi = (ks // 2, ks // 2) if padding is None else padding      # (before, after) on both spatial axes
+    Ho = (H + pad_lo + pad_hi - ks) // stride + 1
+    Wo = (W + pad_lo + pad_hi - ks) // stride + 1
     out = torch.empty(nimg, Ho, Wo, Cout, dtype=_F16, device=x.device)
     d = GemmDesc()
+    if padding is not None:
+        d.pad_lo, d.pad_hi = pad_lo, pad_hi
     d.M, d.N, d.K = nimg * Ho * Wo, Cout, ks * ks * (C1 + C2)
     d.batch0 = d.batch1 = 1
     d.A = x.data_ptr(); d.A2 = x2.data_ptr() if x2 is not None else None
