@@ -161,6 +161,10 @@ int vsx_attention_f16(const void* Q, const void* K, const void* VT, void* O, int
  * (diffusers Attention.get_attention_scores softmax; probs are then handed to the
  * Prompt-to-Prompt controller, attention_register.py:70-76). */
 int vsx_softmax_rows(void* S, int64_t nrows, int64_t ncols, int64_t ld, vsx_stream_t stream);
+/* causal variant for the CLIP text encoder (transformers CLIPAttention with causal_attention_mask): row r is query
+ * r % rows_per_seq and attends to columns <= that index; the other columns get probability 0. */
+int vsx_softmax_rows_causal(void* S, int64_t nrows, int64_t ncols, int64_t ld, int64_t rows_per_seq,
+                            vsx_stream_t stream);
 
 /* K8: temporal self-attention across frames at every spatial site (motion_module.py:287-338),
  * computed directly on the [B, F, HW, heads*d] layout (no transposes).  q/k/v/o share row
@@ -175,6 +179,8 @@ int vsx_temporal_attention_f16(const void* Q, const void* K, const void* V, void
  * ------------------------------------------------------------------------------------------ */
 /* y = silu(x) (resnet.py:172: nonlinearity(temb)) ; n elements */
 int vsx_silu(const void* x, void* y, int64_t n, vsx_stream_t stream);
+/* y = x * sigmoid(1.702 x): CLIP's quick_gelu (text encoder MLP; edlora_util.py:144 runs it 16 x per prompt) */
+int vsx_quick_gelu(const void* x, void* y, int64_t n, vsx_stream_t stream);
 /* y = a + s*b (adapter residual add, unet_blocks.py:399-402; unet.py:434-438) */
 int vsx_axpy(const void* a, const void* b, float s, void* y, int64_t n, vsx_stream_t stream);
 /* Latent layout conversion at the UNet boundary.

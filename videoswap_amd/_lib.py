@@ -62,9 +62,11 @@ PROTOTYPES = {
                               c_int64, c_void_p, c_void_p]),
     'vsx_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 14 + [c_float, c_void_p]),
     'vsx_softmax_rows': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    'vsx_softmax_rows_causal': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     'vsx_temporal_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 9
                                    + [c_float, c_void_p]),
     'vsx_silu': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'vsx_quick_gelu': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'vsx_axpy': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p]),
     'vsx_pack_latents': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     'vsx_unpack_latents': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),

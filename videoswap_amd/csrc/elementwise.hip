@@ -12,6 +12,15 @@ __global__ void silu_kernel(const half_t* __restrict__ x, half_t* __restrict__ y
     if (i < n) y[i] = (half_t)silu_f((float)x[i]);
 }
 
+// CLIP's activation: x * sigmoid(1.702 x)
+__global__ void quick_gelu_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i < n) {
+        const float v = (float)x[i];
+        y[i] = (half_t)(v * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v)));
+    }
+}
+
 __global__ void axpy_kernel(const half_t* __restrict__ a, const half_t* __restrict__ b, float s,
                             half_t* __restrict__ y, long n) {
     const long i = (long)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -117,6 +126,14 @@ extern "C" int vsx_silu(const void* x, void* y, int64_t n, vsx_stream_t stream) 
     hipLaunchKernelGGL(silu_kernel, dim3(blocks_for(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, (const half_t*)x,
                        (half_t*)y, (long)n);
     return vsx_check_launch("vsx_silu");
+}
+
+extern "C" int vsx_quick_gelu(const void* x, void* y, int64_t n, vsx_stream_t stream) {
+    VSX_REQUIRE(x && y && n >= 0, VSX_E_BADSHAPE, "quick_gelu: bad arguments");
+    if (n == 0) return VSX_OK;
+    hipLaunchKernelGGL(quick_gelu_kernel, dim3(blocks_for(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       (const half_t*)x, (half_t*)y, (long)n);
+    return vsx_check_launch("vsx_quick_gelu");
 }
 
 extern "C" int vsx_axpy(const void* a, const void* b, float s, void* y, int64_t n, vsx_stream_t stream) {

@@ -290,6 +290,25 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ 
     for (int c = lane; c < ncols; c += 64) row[c] = (half_t)(__expf((float)row[c] - mx) * inv);
 }
 
+// causal variant (CLIP text encoder: token q attends to tokens <= q): row r belongs to query q = r % rows_per_seq;
+// columns > q get probability 0
+__global__ __launch_bounds__(256) void softmax_rows_causal_kernel(half_t* __restrict__ S, long nrows, int ncols,
+                                                                  long ld, int rows_per_seq) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    half_t* row = S + r * ld;
+    const int live = min(ncols, (int)(r % rows_per_seq) + 1);
+    float mx = -INFINITY;
+    for (int c = lane; c < live; c += 64) mx = fmaxf(mx, (float)row[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < live; c += 64) sum += __expf((float)row[c] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < ncols; c += 64) row[c] = c < live ? (half_t)(__expf((float)row[c] - mx) * inv) : (half_t)0.f;
+}
+
 }  // namespace
 
 extern "C" int64_t vsx_groupnorm_chunks(int64_t rows, int64_t nimg) {
@@ -374,4 +393,14 @@ extern "C" int vsx_softmax_rows(void* S, int64_t nrows, int64_t ncols, int64_t l
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (half_t*)S, (long)nrows, (int)ncols, (long)ld);
     return vsx_check_launch("vsx_softmax_rows");
+}
+
+extern "C" int vsx_softmax_rows_causal(void* S, int64_t nrows, int64_t ncols, int64_t ld, int64_t rows_per_seq,
+                                       vsx_stream_t stream) {
+    VSX_REQUIRE(S != nullptr && ncols > 0 && ld >= ncols && rows_per_seq > 0, VSX_E_BADSHAPE,
+                "softmax_rows_causal: bad arguments");
+    if (nrows == 0) return VSX_OK;
+    hipLaunchKernelGGL(softmax_rows_causal_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (half_t*)S, (long)nrows, (int)ncols, (long)ld, (int)rows_per_seq);
+    return vsx_check_launch("vsx_softmax_rows_causal");
 }

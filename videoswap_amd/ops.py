@@ -183,7 +183,7 @@ def conv2d(x, weight, bias=None, *, x2=None, stride=1, upsample=False, rowvec=No
     return out
 
 
-def attention_scores(q, k, heads, scale, kv_div=1):
+def attention_scores(q, k, heads, scale, kv_div=1, causal=False):
     """probs = softmax(scale * q k^T) materialised (the Prompt-to-Prompt hook path).
 
     q [nb, nq, C], k [nkvb, nk, C] -> probs [nb, heads, nq, nk] (a view of a buffer whose rows are padded to a
@@ -217,7 +217,11 @@ def attention_scores(q, k, heads, scale, kv_div=1):
             d.c_bs0 = heads * nq * ld; d.c_bs1 = nq * ld
             d.alpha = float(scale)
             gemm(d)
-    check(_lib.load().vsx_softmax_rows(_p(buf), nb * heads * nq, nk, ld, _stream()), 'vsx_softmax_rows')
+    if causal:
+        check(_lib.load().vsx_softmax_rows_causal(_p(buf), nb * heads * nq, nk, ld, nq, _stream()),
+              'vsx_softmax_rows_causal')
+    else:
+        check(_lib.load().vsx_softmax_rows(_p(buf), nb * heads * nq, nk, ld, _stream()), 'vsx_softmax_rows')
     return buf[..., :nk]
 
 
@@ -358,6 +362,13 @@ def silu(x):
     _chk(x, 'x')
     y = torch.empty_like(x)
     check(_lib.load().vsx_silu(_p(x), _p(y), x.numel(), _stream()), 'vsx_silu')
+    return y
+
+
+def quick_gelu(x):
+    _chk(x, 'x')
+    y = torch.empty_like(x)
+    check(_lib.load().vsx_quick_gelu(_p(x), _p(y), x.numel(), _stream()), 'vsx_quick_gelu')
     return y
 
 
