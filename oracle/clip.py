@@ -49,6 +49,20 @@ class CLIPTextModel(nn.Module):
                                            for _ in range(num_hidden_layers)])
         tm.final_layer_norm = nn.LayerNorm(hidden_size, eps=layer_norm_eps)
 
+    # the transformers surface convert_edlora_to_diffusers.py:4-33 touches
+    def get_input_embeddings(self):
+        return self.text_model.embeddings.token_embedding
+
+    def resize_token_embeddings(self, n):
+        old = self.text_model.embeddings.token_embedding
+        new = nn.Embedding(n, old.embedding_dim, device=old.weight.device, dtype=old.weight.dtype)
+        with torch.no_grad():
+            new.weight.zero_()
+            k = min(n, old.num_embeddings)
+            new.weight[:k] = old.weight[:k]
+        self.text_model.embeddings.token_embedding = new
+        return new
+
     def forward(self, input_ids):
         tm = self.text_model
         x = tm.embeddings.token_embedding(input_ids) + tm.embeddings.position_embedding.weight[:input_ids.shape[1]]

@@ -1,5 +1,6 @@
 """A/B of the GEMM back ends at the UNet's real shapes: the workgroup-per-tile kernels (option gemm_pp = 0) against the
-persistent ping-pong kernel (gemm_pp = 2) with each of its DMA piece schedules (pp_sched 0/1/2).
+persistent ping-pong kernel with 256-row tiles (gemm_pp = 2), with 128-row tiles (gemm_pp = 3) and the automatic choice
+(gemm_pp = 1, what the product runs).
 
     python tools/gemm_ab.py [--batch 2] [--rounds 5] > gpurun_out/gemm_ab.txt
 
@@ -83,7 +84,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--reps', type=int, default=4)
     args = ap.parse_args()
-    variants = [('tile', 0, 0), ('pp/s0', 2, 0), ('pp/s1', 2, 1), ('pp/s2', 2, 2)]
+    variants = [('tile', 0, 0), ('pp256', 2, 0), ('pp128', 3, 0), ('auto', 1, 0)]
     print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
     print(f'{"shape":44s} {"n":>3s} ' + ' '.join(f'{v[0]:>8s}' for v in variants) + '   best TF/s  speedup  fwd-ms tile -> best')
     tot_old = tot_best = 0.0

@@ -154,6 +154,12 @@ class _DDIMBase:
     def from_config(cls, config, **kwargs):
         return cls(**{**dict(config), **kwargs})
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, **kwargs):
+        """`<path>/<subfolder>/scheduler_config.json` (test.py:77)"""
+        from .formats import scheduler_config_from_pretrained
+        return cls(**{**scheduler_config_from_pretrained(pretrained_model_path, subfolder), **kwargs})
+
     def scale_model_input(self, sample, timestep=None):
         return sample
 

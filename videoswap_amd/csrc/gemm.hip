@@ -1043,10 +1043,12 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     // VSX_GEMM_PP=0 disables it (A/B measurements against the workgroup-per-tile kernels), 2 forces it whenever the
     // shape is eligible.
     const int pp = pp_mode();
-    const bool pp_ok = pp != 0 && wide && nbatch == 1 && (splits <= 1 || pp == 2) && !force_tile() && pp_supported(p);
-    if (pp_ok && (blocks(256, 320) >= 224 || (pp == 2 && blocks(256, 320) >= 64))) {
+    const bool pp_ok = pp != 0 && wide && nbatch == 1 && (splits <= 1 || pp >= 2) && !force_tile() && pp_supported(p);
+    // option gemm_pp: 0 never, 1 automatic (thresholds from tools/gemm_ab.py: profiles/r02_gemm_ab_*.txt), 2 = 256-row
+    // tiles wherever >= 64 of them exist (else 128-row), 3 = 128-row tiles wherever >= 32 exist
+    if (pp_ok && pp != 3 && (blocks(256, 320) >= 200 || (pp == 2 && blocks(256, 320) >= 64))) {
         rc = launch_pp(p, 256, stream);
-    } else if (pp_ok && (blocks(128, 320) >= 224 || (pp == 2 && blocks(128, 320) >= 32))) {
+    } else if (pp_ok && pp >= 2 && blocks(128, 320) >= 32) {
         rc = launch_pp(p, 128, stream);
     } else if (force_tile() && wide) {
         p.ws = (float*)d->workspace;

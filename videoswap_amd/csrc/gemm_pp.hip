@@ -27,7 +27,8 @@
 // has waited for its ds_reads (lgkmcnt(0)) before the barrier that precedes G0's L0(t), the first phase that issues
 // a piece of slab t+1.  Every wave waits for its own pieces (vmcnt(0)) before the barrier that precedes G0's L0(t+1):
 // G0 at the end of M3(t), G1 at the end of L3(t).
-// At a tile boundary both groups run the epilogue in the SAME barrier interval (G0: |B| E L0' |B|, G1: M3 E |B| L0').
+// At a tile boundary both groups run the epilogue in the SAME barrier interval and then resynchronise
+// (G0: |B| E |B| L0' |B| ..., G1: M3 E |B| |B| L0' ...).
 //
 // Register budget (256 per lane, nothing may spill: a scratch reload is a VMEM op and would queue behind the DMA
 // pieces in flight): 160 accumulators + 28 fragment registers; row offsets are NOT kept per piece — a piece's row base
@@ -50,113 +51,136 @@ __device__ __forceinline__ kparams_t kernarg_params() {
 }
 
 // Epilogue of one wave: TM x 5 C^T accumulator tiles (acc[j][i]: lane (l31, hi) owns output row mrow0 + i*32 + l31;
-// register quad g of tile (j, i) holds the 4 consecutive columns ncol0 + j*32 + 8g + 4hi ..).  The host routes a
-// problem here only when every row / column octet is 16-byte aligned and N is a multiple of 160 (GEGLU) / 320, so
-// there is no column edge; rows >= M are skipped.
-template <int TM>
-__device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], const int mrow0, const int ncol0, const int gcol0,
-                                            const int l31, const int hi) {
-    constexpr int TN = 5;
-    kparams_t p = kernarg_params();
+// register quad g of tile (j, i) holds the 4 consecutive columns ncol0 + j*32 + 8g + 4hi ..).
+//
+// Writing C straight from that layout costs more than the main loop of a K <= 1280 problem: every store instruction
+// touches 32 different rows with 2 x 16 bytes each (64 partial lines; measured 4.5 B/clk/CU, 36 k cycles per 256x320
+// tile against 13 k for its five K slabs), and the residual is read the same way.  So the tile goes through a
+// wave-private LDS staging area (fp32, 32 rows x 64 columns at a time, rows padded by 16 B: conflict-free
+// ds_write_b128 from the fragment layout) and is read back ROW-MAJOR: a lane then owns 8 consecutive columns of one
+// row, 8 lanes cover one full 128-byte line, and bias / row vector / residual are added in that layout — same
+// fp32 operation order as gemm.hip's epilogue, so the results stay bit-identical to the tile kernels.
+// The host routes a problem here only when every row / column octet is 16-byte aligned and N is a multiple of 160
+// (GEGLU) / 320, so there is no column edge; rows >= M are skipped.
+constexpr int EP_BYTES = 10240;     // staging bytes per wave: 32 rows x (64 + 4) floats = 8704
+
+template <int CW>                   // chunk width in output columns: 64, 32 or 16
+__device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, const int lane, const int mblk,
+                                              const int ncol, const bool add_bias) {
+    constexpr int STRIDE = CW + 4;                  // floats per staged row
+    constexpr int LPR = CW / 8;                     // lanes per row (8 columns each)
+    constexpr int RPP = 64 / LPR;                   // rows per pass
     const int Mi = (int)p->M, Ni = (int)p->N;
-    const int ldc = (int)p->ldc;
+    const int col8 = (lane % LPR) * 8, r0 = lane / LPR;
+    const int n = ncol + col8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (add_bias && p->bias) {
+        const h8 b = *reinterpret_cast<const h8*>(p->bias + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (float)b[e];
+    }
+    const half_t* rvp = p->rowvec;
+    const half_t* resp = p->residual;
+    half_t* cp = p->C;
+    const unsigned ldc = (unsigned)p->ldc, ldr = (unsigned)p->ldr, rpv = (unsigned)p->rows_per_vec;
+#pragma unroll
+    for (int pass = 0; pass < 32 / RPP; ++pass) {
+        const int row = pass * RPP + r0;
+        const int m = mblk + row;
+        if (m >= Mi) continue;
+        const f4v a = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8);
+        const f4v b = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8 + 4);
+        float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (add_bias && p->bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += bv[e];
+        }
+        if (rvp) {
+            const h8 v = *reinterpret_cast<const h8*>(rvp + ((unsigned)m / rpv) * (unsigned)Ni + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += (float)v[e];
+        }
+        if (resp) {
+            const h8 v = *reinterpret_cast<const h8*>(resp + (unsigned)m * ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += (float)v[e];
+        }
+        h8 pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = (half_t)o[e];
+        *reinterpret_cast<h8*>(cp + (unsigned)m * ldc + n) = pk;
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, const int mrow0, const int ncol0,
+                                            const int gcol0, const int lane) {
+    kparams_t p = kernarg_params();
+    const int l31 = lane & 31, hi = lane >> 5;
     const float alpha = p->alpha;
-    const half_t* bias = p->bias;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = mrow0 + i * 32 + l31;
-        if (m >= Mi) continue;
-        half_t* crow = p->C + (unsigned)m * (unsigned)ldc;
-        const half_t* rrow = p->residual ? p->residual + (unsigned)m * (unsigned)p->ldr : nullptr;
+        const int mblk = mrow0 + i * 32;
         if (p->geglu) {
-            // tile j: registers 0-7 are h of 16 output columns, registers 8-15 the matching g
+            // tile j: registers 0-7 are h of 16 output columns, registers 8-15 the matching g.  The activation (which
+            // needs the bias first) is computed in the fragment layout; chunks: j = 0..3 (64 columns), j = 4 (16)
+            const half_t* bias = p->bias;
+            const int Ni = (int)p->N;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+            for (int c = 0; c < 2; ++c) {
+                const int j0 = c * 4, nj = c ? 1 : 4;
+                const int stride = nj * 16 + 4;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int nb = gcol0 + j * 16 + 8 * q + 4 * hi;
-                    float hv[4], gv[4];
+                for (int jj = 0; jj < nj; ++jj) {
+                    const int j = j0 + jj;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        hv[e] = acc[j][i][4 * q + e] * alpha;
-                        gv[e] = acc[j][i][8 + 4 * q + e] * alpha;
+                    for (int q = 0; q < 2; ++q) {
+                        const int nb = gcol0 + j * 16 + 8 * q + 4 * hi;
+                        float hv[4], gv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hv[e] = acc[j][i][4 * q + e] * alpha;
+                            gv[e] = acc[j][i][8 + 4 * q + e] * alpha;
+                        }
+                        if (bias) {
+                            const h4 bh = *reinterpret_cast<const h4*>(bias + nb);
+                            const h4 bg = *reinterpret_cast<const h4*>(bias + Ni + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { hv[e] += (float)bh[e]; gv[e] += (float)bg[e]; }
+                        }
+                        f4v o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
+                        *reinterpret_cast<f4v*>(stg + l31 * stride + jj * 16 + 8 * q + 4 * hi) = o;
                     }
-                    if (bias) {
-                        const h4 bh = *reinterpret_cast<const h4*>(bias + nb);
-                        const h4 bg = *reinterpret_cast<const h4*>(bias + Ni + nb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { hv[e] += (float)bh[e]; gv[e] += (float)bg[e]; }
-                    }
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
-                    if (rrow) {
-                        const h4 b = *reinterpret_cast<const h4*>(rrow + nb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
-                    }
-                    h4 pk;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)o[e];
-                    *reinterpret_cast<h4*>(crow + nb) = pk;
+                    __builtin_amdgcn_sched_barrier(0);   // one accumulator tile at a time (register pressure)
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one accumulator tile at a time (register pressure)
+                if (c == 0) epilogue_rows<64>(p, stg, lane, mblk, gcol0, false);
+                else epilogue_rows<16>(p, stg, lane, mblk, gcol0 + 64, false);
+                __builtin_amdgcn_sched_barrier(0);
             }
             continue;
         }
-        const half_t* rv = p->rowvec ? p->rowvec + ((unsigned)m / (unsigned)p->rows_per_vec) * (unsigned)Ni : nullptr;
+        // plain: chunks j = {0, 1}, {2, 3} (64 columns: one full 128-byte line per row), {4} (32 columns)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nt = ncol0 + j * 32;
-            // the lane pair (l, l+32) exchanges register quads with v_permlane32_swap so that each lane owns 8
-            // consecutive columns: 16-byte stores / residual loads (the row-per-lane epilogue is store-ISSUE-bound)
-            unsigned pkw[4][2];
-            h4 rq[4];
-            if (rrow) {
+        for (int c = 0; c < 3; ++c) {
+            const int j0 = c * 2, nj = c < 2 ? 2 : 1;
+            const int stride = nj * 32 + 4;
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(rrow + nt + 16 * a + 8 * hi);
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
-                    rq[2 * a] = __builtin_bit_cast(h4, make_uint2(s0[0], s1[0]));
-                    rq[2 * a + 1] = __builtin_bit_cast(h4, make_uint2(s0[1], s1[1]));
+            for (int jj = 0; jj < nj; ++jj) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f4v o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[j0 + jj][i][4 * g + e] * alpha;
+                    *reinterpret_cast<f4v*>(stg + l31 * stride + jj * 32 + 8 * g + 4 * hi) = o;
                 }
             }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = nt + 8 * g + 4 * hi;
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = acc[j][i][4 * g + e] * alpha;
-                if (bias) {
-                    const h4 b = *reinterpret_cast<const h4*>(bias + nb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
-                }
-                if (rv) {
-                    const h4 b = *reinterpret_cast<const h4*>(rv + nb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
-                }
-                if (rrow) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += (float)rq[g][e];
-                }
-                h4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (half_t)o[e];
-                const uint2 w = __builtin_bit_cast(uint2, pk);
-                pkw[g][0] = w.x;
-                pkw[g][1] = w.y;
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                // quads 2a (columns 16a + 4hi ..) and 2a+1 (16a + 8 + 4hi ..): after the swap the lower lane of
-                // the pair holds columns 16a .. 16a+7, the upper lane 16a+8 .. 16a+15
-                const auto s0 = __builtin_amdgcn_permlane32_swap(pkw[2 * a][0], pkw[2 * a + 1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(pkw[2 * a][1], pkw[2 * a + 1][1], false, false);
-                *reinterpret_cast<uint4*>(crow + nt + 16 * a + 8 * hi) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < 2) epilogue_rows<64>(p, stg, lane, mblk, ncol0 + j0 * 32, true);
+            else epilogue_rows<32>(p, stg, lane, mblk, ncol0 + j0 * 32, true);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -174,6 +198,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     constexpr int GB = 5;                       // B pieces per wave and slab
     constexpr int NPIECE = GA + GB;
     constexpr int STAGE = (BM + BN) * 128;      // bytes per ring slot
+    constexpr int NFIT = STAGE / EP_BYTES;      // waves whose epilogue staging area fits a ring slot
     constexpr int OOB_OFF = (int)0x80000000;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -445,15 +470,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             if (G == 0) wait_vmcnt<0>();        // G0's pieces: waited behind its last MFMAs
             if (kt + 1 < nk) bar();
         }
-        // ---- tile boundary: both groups run the epilogue in the same barrier interval ----
+        // ---- tile boundary: both groups run the epilogue in the same barrier interval (G0: |B| E, G1: M3 E), then
+        // meet at a barrier — the epilogue stages C through the ring slot the tile's last slab occupied (waves
+        // 0..NFIT-1) and the LDS behind the ring (the others), and G0's next load phase issues DMA into that slot —
+        // and G1 drops one phase behind again.  (The other slot holds slab 0 of the next tile, already landed.) ----
         if (G == 0) bar();
         {
             const int tile = tile0 + c_t * wgx;
             const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
             const int n0 = geglu ? tile_n * (BN / 2) : tile_n * BN;
-            epilogue_pp<TM>(acc, tile_m * BM + wr * WM, n0 + wc * WN, n0 + wc * TN * 16, l31, hi);
+            const int stg_off = wave < NFIT ? ((c_g - 1) & 1) * STAGE + wave * EP_BYTES
+                                            : 2 * STAGE + (wave - NFIT) * EP_BYTES;
+            epilogue_pp<TM>(acc, reinterpret_cast<float*>(smem + stg_off), tile_m * BM + wr * WM, n0 + wc * WN,
+                            n0 + wc * TN * 16, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
+        lgkm0();
+        bar();
         if (G == 1) bar();
     }
     if (G == 0) bar();                          // matches group 1's extra barrier at the start
@@ -461,7 +494,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
 
 template <int TM, bool CONV, int CUT1, int CUT2>
 int launch_one(const GemmParams& p, hipStream_t stream) {
-    constexpr size_t smem = 2 * (size_t)(128 * TM + 320) * 128;
+    constexpr size_t stage = (size_t)(128 * TM + 320) * 128;
+    constexpr size_t smem = 2 * stage + (8 - stage / EP_BYTES) * EP_BYTES;     // ring + the staging areas behind it
+    static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TM, CONV, CUT1, CUT2>),
@@ -490,6 +525,7 @@ bool pp_supported(const GemmParams& p) {
     const long cols = p.geglu ? 2 * p.N : p.N;
     if (cols % 320 != 0 || p.c_mode != 0 || p.splitk > 1) return false;
     if (!p.vec8 || (p.residual && !p.rvec8)) return false;
+    if (!vsx_aligned16(p.bias) || !vsx_aligned16(p.rowvec)) return false;      // 16-byte epilogue loads
     if (p.geglu && p.rowvec) return false;
     if (p.a_mode == 1) {
         const int ctot = p.C1 + p.C2;

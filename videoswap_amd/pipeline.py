@@ -44,11 +44,36 @@ class VideoSwapPipeline:
         self.unet, self.scheduler, self.adapter = unet, scheduler, adapter
         # pipeline_videoswap.py:163 — the inverse scheduler is always rebuilt from the sampler's config
         self.inverse_scheduler = DDIMInverseScheduler.from_config(scheduler.config)
-        self.vae_scale_factor = 8
+        boc = getattr(getattr(vae, 'config', None), 'block_out_channels', None)
+        self.vae_scale_factor = 2 ** (len(boc) - 1) if boc else 8         # pipeline_videoswap.py:164
+        from .vae import VaeImageProcessor
+        self.image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor)
         self.new_concept_cfg = None
         self.store_controller = AttentionStore()
         self.empty_controller = EmptyControl()
         self._device = torch.device('cpu')
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, unet=None, adapter=None, scheduler=None, torch_dtype=None,
+                        vae=None, text_encoder=None, tokenizer=None, **unused):
+        """StableDiffusionPipeline.from_pretrained as test.py:73-80 calls it: the components passed in are used as they
+        are, the others (`vae/`, `text_encoder/`, `tokenizer/`, `scheduler/`) are loaded from the SD-layout directory."""
+        from .clip import CLIPTextModel, load_tokenizer
+        from .compat import DDIMScheduler
+        from .vae import AutoencoderKL
+        if vae is None:
+            vae = AutoencoderKL.from_pretrained(pretrained_model_path, subfolder='vae', torch_dtype=torch_dtype)
+        if text_encoder is None:
+            text_encoder = CLIPTextModel.from_pretrained(pretrained_model_path, subfolder='text_encoder',
+                                                         torch_dtype=torch_dtype)
+        if tokenizer is None:
+            tokenizer = load_tokenizer(pretrained_model_path)
+        if scheduler is None:
+            scheduler = DDIMScheduler.from_pretrained(pretrained_model_path, subfolder='scheduler')
+        if unet is None:
+            raise ValueError('VideoSwapPipeline.from_pretrained: pass the AnimateDiffUNet3DModel as `unet` (test.py:55-64)')
+        return cls(vae=vae, text_encoder=text_encoder, tokenizer=tokenizer, unet=unet, scheduler=scheduler,
+                   adapter=adapter)
 
     # ---- small protocol surface of diffusers' DiffusionPipeline that test.py touches ----
     def to(self, device=None, dtype=None):
@@ -144,10 +169,10 @@ class VideoSwapPipeline:
         device = self._execution_device
         do_cfg = guidance_scale > 1.0
         if latents is None:
-            if torch.is_tensor(video):
-                latents = self.prepare_image_latents(video, video.shape[0], self.unet.dtype, device, generator)
-            else:
-                raise ValueError('invert: pass `latents` [1,4,F,h,w] or a [F,4,h,w] latent tensor as `video`')
+            if video is None:
+                raise ValueError('invert: pass `latents` [1,4,F,h,w], a [F,4,h,w] latent tensor or frames as `video`')
+            video = self.image_processor.preprocess(video)        # PIL list -> [F,3,H,W] in [-1,1]; tensors pass
+            latents = self.prepare_image_latents(video, video.shape[0], self.unet.dtype, device, generator)
         latents = latents.to(device=device, dtype=self.unet.dtype).contiguous()
         prompt_embeds = self._encode_prompt(prompt, device, 1, do_cfg, prompt_embeds=prompt_embeds)
 
@@ -278,8 +303,9 @@ class VideoSwapPipeline:
             video = latents
         else:
             b, c, f, h, w = latents.shape
-            flat = latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+            flat = latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)       # 'b c f h w -> (b f) c h w'
             video = self.vae.decode(flat / self.vae.config.scaling_factor, return_dict=False)[0]
+            video = self.image_processor.postprocess(video, output_type=output_type)
         if not return_dict:
             return video
         return VideoSwapPipelineOutput(videos=video)

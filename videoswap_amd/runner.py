@@ -1,0 +1,135 @@
+"""`test.py -opt <yml>` of the reference (test.py:24-136) on this package: the same steps in the same order — UNet from
+the SD directory + motion-module checkpoint, point adapter, pipeline assembly from the SD directory, dataset, ED-LoRA
+concept cfg, `validation`, result files — without `accelerate` (one process, one GPU).
+
+    python -m videoswap_amd.runner -opt options/test_videoswap/animal/2001_catheadturn_T05_Iter100/....yml
+        [--set datasets.num_frames=4 --set val.editing_config.num_inference_steps=2]   # BASELINE.json configs[0]
+
+Relative paths in the YAML are resolved against the current directory, as in the reference; results go to
+`$VSX_RESULTS_ROOT` (default: ./results)/<name>/visualization.  The reference's own `test.py` runs UNCHANGED on the
+same code through `python -m videoswap_amd.dropin /path/to/test.py -opt <yml>` (shim packages `diffusers`,
+`omegaconf`, `videoswap.*`)."""
+import argparse
+import json
+import os
+import random
+
+import torch
+
+from . import build_model, build_pipeline, formats
+from .compat import DDIMScheduler
+from .config import OmegaConf, load_options
+from .data import build_dataset
+from .edlora import revise_edlora_unet_attention_forward
+from .utils import dict2str, save_video_to_dir, set_path_logger
+
+
+def set_seed(seed):
+    random.seed(seed)
+    try:
+        import numpy as np
+        np.random.seed(seed % (2 ** 32))
+    except ImportError:      # pragma: no cover
+        pass
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def build_from_options(opt, device='cuda', classes=None):
+    """test.py:45-91 — returns (pipeline, adapter, weight_dtype).  `classes` may override the model classes by
+    registry name (tests run the same orchestration on the CPU oracle)."""
+    classes = classes or {}
+    mixed = opt.get('mixed_precision', 'no')
+    weight_dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(mixed, torch.float32)
+
+    unet_opt = dict(opt['models']['unet'])
+    unet_type = unet_opt.pop('type')
+    if unet_type != 'AnimateDiffUNet3DModel':
+        raise NotImplementedError(unet_type)
+    unet_cls = classes.get(unet_type) or build_model(unet_type)
+    kwargs = OmegaConf.to_container(OmegaConf.load(unet_opt.pop('inference_config_path')).unet_additional_kwargs)
+    unet = unet_cls.from_pretrained_2d(opt['path']['pretrained_model_path'], subfolder='unet',
+                                       unet_additional_kwargs=kwargs)
+    if unet_opt.get('motion_module_path'):
+        sd = formats.rename_motion_module_keys(torch.load(unet_opt['motion_module_path'], map_location='cpu'))
+        unet.load_state_dict(sd, strict=False)
+
+    adapter_opt = dict(opt['models']['adapter'])
+    adapter_type = adapter_opt.pop('type')
+    adapter_cls = classes.get(adapter_type) or build_model(adapter_type)
+    adapter = adapter_cls(**OmegaConf.to_container(OmegaConf.load(adapter_opt['model_config_path'])))
+    adapter.load_state_dict(torch.load(opt['path']['pretrained_adapter_path'], map_location='cpu'))
+    adapter = adapter.to(dtype=weight_dtype)
+
+    pipe_cls = classes.get(opt['val']['val_pipeline']) or build_pipeline(opt['val']['val_pipeline'])
+    pipe = pipe_cls.from_pretrained(
+        opt['path']['pretrained_model_path'], unet=unet.to(dtype=weight_dtype), adapter=adapter,
+        scheduler=DDIMScheduler.from_pretrained(opt['path']['pretrained_model_path'], subfolder='scheduler'),
+        torch_dtype=weight_dtype).to(device)
+    pipe.enable_vae_slicing()
+
+    cfg = formats.read_new_concept_cfg(opt['path']['pretrained_model_path'])
+    if cfg is not None:
+        revise_edlora_unet_attention_forward(pipe.unet)
+        pipe.set_new_concept_cfg(cfg)
+    pipe.scheduler.set_timesteps(opt['val']['editing_config']['num_inference_steps'])
+    return pipe, adapter, weight_dtype
+
+
+def test(root_path, opt, opt_path, device='cuda', classes=None, save=True):
+    """test.py:24-124.  Returns (edited_results, visualization dir)."""
+    set_path_logger(None, root_path, opt_path, opt, is_train=False)
+    print(dict2str(opt))
+    if opt.get('manual_seed') is None:
+        opt['manual_seed'] = random.randint(1, 10000)
+    set_seed(opt['manual_seed'])
+
+    pipe, adapter, weight_dtype = build_from_options(opt, device, classes)
+
+    dataset_opt = opt['datasets']
+    dataset_type = dataset_opt.pop('type')
+    dataset = build_dataset(dataset_type)(dataset_opt)
+    frames = dataset.get_frames()
+    conditions = None
+    if adapter is not None:
+        adapter.eval()
+        conditions = dataset.get_conditions()
+
+    edited = pipe.validation(source_video=frames, source_conditions=conditions, source_prompt=opt['datasets']['prompt'],
+                             editing_config=opt['val']['editing_config'], dtype=weight_dtype, train_dataset=dataset,
+                             save_dir=opt['path']['visualization'])
+    save_dir = opt['path']['visualization']
+    if save:
+        kind, fps = opt['val'].get('save_type', 'frame_gif'), opt['val'].get('fps', 8)
+        save_video_to_dir(frames, save_dir=os.path.join(save_dir, 'source'), save_suffix='source', save_type=kind, fps=fps)
+        for key, video in edited.items():
+            if not isinstance(video, list):
+                continue                         # latent outputs (no VAE plugged in) are returned, not written
+            out_dir = save_dir if 'frame' not in kind else os.path.join(save_dir, key)
+            suffix = f"{key}_{opt['name']}" if opt['val'].get('use_suffix', False) else f'{key}'
+            save_video_to_dir(video, save_dir=out_dir, save_suffix=suffix, save_type=kind, fps=fps)
+    return edited, save_dir
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('-opt', type=str, required=True)
+    ap.add_argument('--set', action='append', default=[], metavar='dotted.key=json', help='override an option')
+    ap.add_argument('--device', default='cuda')
+    args = ap.parse_args(argv)
+    overrides = {}
+    for item in args.set:
+        k, v = item.split('=', 1)
+        try:
+            overrides[k] = json.loads(v)
+        except json.JSONDecodeError:
+            overrides[k] = v
+    opt = load_options(args.opt, overrides)
+    root = os.path.abspath(os.getcwd())
+    _, out = test(root, opt, args.opt, device=args.device)
+    print('results in', out)
+
+
+if __name__ == '__main__':
+    main()
