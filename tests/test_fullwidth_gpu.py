@@ -92,11 +92,11 @@ def _check(name, prod_out, ref, half_out, extra=None):
     assert worst <= 4 * e16, f'{name}: worst frame rel-L2 {worst:.3e} vs fp16-storage oracle error {e16:.3e}'
 
 
-def test_forward_64x64_bf16_vs_host_oracle(models):
-    """(1) B = 2, T = 8, 64x64: M = 65 536 rows at the top level -> 256x320 conv tile, N = 4096 flash attention,
-    MFMA temporal attention, split-K at the 8x8 level.  fp32 oracle on the host cores."""
+def test_forward_vs_host_oracle(models):
+    """(1) B = 1, T = 2, 64x64 with the fp32 oracle on the HOST cores (~40 s on the 128-core box): anchors the
+    device-placed fp32 oracle the larger cases use, and checks the product against the host oracle directly."""
     cfg, ora, ora_dev, ora_h, prod = models
-    x, txt = _inputs(2, 8, 64, 64, seed=101)
+    x, txt = _inputs(1, 2, 64, 64, seed=101)
     t0 = time.time()
     torch.set_num_threads(os.cpu_count() or 1)
     ref = _fwd(ora, x, 481, txt)
@@ -105,8 +105,17 @@ def test_forward_64x64_bf16_vs_host_oracle(models):
     e_dev = rel_l2(ref_dev, ref)
     print(f'host fp32 oracle {host_s:.1f} s on {os.cpu_count()} cores; device-placed fp32 oracle vs host: {e_dev:.2e}')
     assert e_dev < 2e-4, 'the device-placed fp32 oracle must agree with the host oracle'
-    _check('unet_B2_T8_64x64_vs_host_fp32_oracle', _fwd(prod, x, 481, txt), ref, _fwd(ora_h, x, 481, txt),
+    _check('unet_B1_T2_64x64_vs_host_fp32_oracle', _fwd(prod, x, 481, txt), ref, _fwd(ora_h, x, 481, txt),
            extra=dict(host_oracle_s=host_s, device_oracle_vs_host=e_dev))
+
+
+def test_forward_64x64_B2_T8(models):
+    """(1b) B = 2, T = 8, 64x64: M = 65 536 rows at the top level -> big-tile convolutions, N = 4096 flash attention,
+    MFMA temporal attention, split-K at the 8x8 level.  (Round-2 run 1 also checked this shape against the HOST
+    oracle: rel-L2 1.30e-3, device-placed oracle vs host 1.7e-6 — profiles/r02_parity_fullwidth.json.)"""
+    cfg, ora, ora_dev, ora_h, prod = models
+    x, txt = _inputs(2, 8, 64, 64, seed=111)
+    _check('unet_B2_T8_64x64', _fwd(prod, x, 481, txt), _fwd(ora_dev, x, 481, txt), _fwd(ora_h, x, 481, txt))
 
 
 def test_forward_benchmark_shape(models):
