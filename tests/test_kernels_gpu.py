@@ -413,6 +413,9 @@ def test_attention_scores_and_pv(nb, heads, nq, nk, d, kv_div):
 
 @pytest.mark.parametrize('B,fq,fk,hw,heads,d', [(2, 16, 16, 64, 8, 40), (1, 4, 4, 256, 8, 80), (2, 16, 16, 16, 8, 160),
                                                (2, 16, 16, 4096, 8, 40), (1, 8, 8, 1024, 8, 80),
+                                               # long-clip mode: local query frames x gathered key frames (MFMA kernel)
+                                               (1, 16, 64, 256, 8, 40), (2, 16, 64, 64, 8, 80), (1, 16, 64, 16, 8, 160),
+                                               (1, 8, 40, 50, 8, 40), (1, 24, 96, 10, 8, 80), (1, 16, 128, 8, 6, 40),
                                                (1, 4, 16, 30, 2, 8), (1, 24, 24, 10, 4, 16)])
 def test_temporal_attention(B, fq, fk, hw, heads, d):
     C = heads * d

@@ -9,6 +9,8 @@ python -c "from videoswap_amd import _lib; l=_lib.load(); print('lib ok', l.vsx_
 timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k persistent -rf > $O/${TAG}_pp_tests.log 2>&1
 PP_RC=$?
 tail -n 4 $O/${TAG}_pp_tests.log
+timeout 200 python -m pytest tests/test_kernels_gpu.py -q -k "temporal or big or benchmark_shape" -rf > $O/${TAG}_kernel_tests.log 2>&1
+tail -n 6 $O/${TAG}_kernel_tests.log | cut -c1-300
 if [ $PP_RC -ne 0 ]; then
   echo "persistent kernel tests rc=$PP_RC: rest of the call runs with VSX_GEMM_PP=0"
   export VSX_GEMM_PP=0

@@ -558,6 +558,157 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const TempParam
     }
 }
 
+// Long-clip form of the matrix-core kernel (frame-sharded mode): fq local query frames (<= 32) against
+// fk gathered key frames (<= 128).  G = 32 / fq heads are packed along the QUERY dimension only; for every packed head
+// g and every block of 32 keys one S^T tile [32 keys of head g] x [(g', query)] is computed and a column keeps it iff
+// g == g'; the softmax then runs over the column's own 32*NKB score registers, and the second product walks the same
+// (g, key block) pairs with P zeroed for the other heads' columns.  V^T tiles go through the wave-private LDS tile one
+// (head, key block) at a time.
+template <int D>
+__global__ __launch_bounds__(256) void temporal_attn_mfma_long_kernel(const TempParams p) {
+    constexpr int DK = (D + 15) / 16;
+    constexpr int DT = (D + 31) / 32;
+    constexpr int DV = D / 8;
+    constexpr int VSTR = 40;
+    constexpr int NVL = (32 * DV + 63) / 64;
+    constexpr int NKB = 4;                 // key blocks of 32 held in registers: fk <= 128
+    __shared__ __attribute__((aligned(16))) half_t smem[4][DT * 32 * VSTR];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int fq = p.fq, fk = p.fk;
+    const int G = 32 / fq;
+    const int nkb = (fk + 31) >> 5;
+    const long site = blockIdx.x;
+    const long b = blockIdx.z;
+    const int head0 = ((int)blockIdx.y * 4 + wave) * G;
+    if (head0 >= p.heads) return;          // waves are independent: no barrier below
+    half_t* sVT = smem[wave];
+
+    const int qg = l31 / fq, qf_ = l31 - qg * fq;
+    const bool qok = qg < G && head0 + qg < p.heads;
+    const half_t* qptr = p.Q + ((b * fq + qf_) * p.hw + site) * p.ldq + (long)(head0 + qg) * D + hi * 8;
+    h8 qb[DK];
+#pragma unroll
+    for (int t = 0; t < DK; ++t)
+        qb[t] = (qok && t * 16 + hi * 8 < D) ? as_h8(ld16(qptr + t * 16)) : as_h8(make_uint4(0, 0, 0, 0));
+
+    const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16v sc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) sc[kb] = zero;
+    const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);      // MFMA row r carries key swap23(r)
+    for (int g = 0; g < G; ++g) {
+        if (head0 + g >= p.heads) break;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nkb) continue;
+            const int key = kb * 32 + krow;
+            const half_t* kptr = p.K + ((b * fk + key) * p.hw + site) * p.ldkv + (long)(head0 + g) * D + hi * 8;
+            f16v tile = zero;
+#pragma unroll
+            for (int t = 0; t < DK; ++t) {
+                const h8 ka = (key < fk && t * 16 + hi * 8 < D) ? as_h8(ld16(kptr + t * 16)) : as_h8(make_uint4(0, 0, 0, 0));
+                tile = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb[t], tile, 0, 0, 0);
+            }
+            if (g == qg) sc[kb] = tile;
+        }
+    }
+
+    // ---- softmax over the fk keys of this column (register r of block kb holds key 32 kb + (r&3) + 4((r>>2)&1) + 8 hi + 16 (r>>3)) ----
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
+            const bool v = qok && kb < nkb && key < fk;
+            sc[kb][r] = v ? sc[kb][r] * sl2 : -INFINITY;
+            mx = fmaxf(mx, sc[kb][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[kb][r] = __builtin_amdgcn_exp2f(sc[kb][r] - mx);
+            sum += sc[kb][r];
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+    // ---- O^T = sum over (head g, key block) of V^T[c, keys] . P^T[keys, (g', query)], P = 0 where g' != g ----
+    f16v o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = zero;
+    for (int g = 0; g < G; ++g) {
+        if (head0 + g >= p.heads) break;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nkb) continue;
+            uint4 raw[NVL];
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const int u = lane + 64 * i;
+                const int kk = u / DV, ch = u - kk * DV;
+                const int key = kb * 32 + kk;
+                raw[i] = (u < 32 * DV && key < fk)
+                             ? ld16(p.V + ((b * fk + key) * p.hw + site) * p.ldkv + (long)(head0 + g) * D + ch * 8)
+                             : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const int u = lane + 64 * i;
+                if (u < 32 * DV) {
+                    const int kk = u / DV, ch = u - kk * DV;
+                    const h8 v = as_h8(raw[i]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sVT[(ch * 8 + e) * VSTR + kk] = v[e];
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                h8 pf;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[jj] = g == qg ? (half_t)sc[kb][8 * s2 + jj] : (half_t)0.f;
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const h8 vf = *reinterpret_cast<const h8*>(sVT + (t * 32 + l31) * VSTR + 16 * s2 + 8 * hi);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (qok) {
+        half_t* orow = p.O + ((b * fq + qf_) * p.hw + site) * p.ldo + (long)(head0 + qg) * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = t * 32 + 8 * g4 + 4 * hi;
+                if (c < D) {
+                    h4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g4 + e] * inv);
+                    *reinterpret_cast<h4*>(orow + c) = pk;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch_temporal_mfma_long(const TempParams& p, long B, hipStream_t stream) {
+    const int G = 32 / p.fq;
+    const int groups = (p.heads + G - 1) / G;
+    dim3 grid((unsigned)p.hw, (unsigned)((groups + 3) / 4), (unsigned)B);
+    hipLaunchKernelGGL((temporal_attn_mfma_long_kernel<D>), grid, dim3(256), 0, stream, p);
+    return vsx_check_launch("vsx_temporal_attention_f16");
+}
+
 template <int D>
 int launch_temporal_mfma(const TempParams& p, long B, hipStream_t stream) {
     const int G = 32 / (p.fq > p.fk ? p.fq : p.fk);
@@ -631,6 +782,10 @@ extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const vo
         if (d == 40) return launch_temporal_mfma<40>(p, B, (hipStream_t)stream);
         if (d == 80) return launch_temporal_mfma<80>(p, B, (hipStream_t)stream);
         if (d == 160) return launch_temporal_mfma<160>(p, B, (hipStream_t)stream);
+    } else if (fq <= 32 && fk <= 128) {    // long-clip mode: local query frames against the gathered key frames
+        if (d == 40) return launch_temporal_mfma_long<40>(p, B, (hipStream_t)stream);
+        if (d == 80) return launch_temporal_mfma_long<80>(p, B, (hipStream_t)stream);
+        if (d == 160) return launch_temporal_mfma_long<160>(p, B, (hipStream_t)stream);
     }
     const size_t slice = (((size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float)) + 15) & ~(size_t)15;
     const size_t smem = 4 * slice;
