@@ -223,6 +223,31 @@ int vsx_prof_enable(int64_t on, int64_t max_samples);
 int vsx_prof_pause(int64_t paused);
 int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* total_flop);
 
+/* ------------------------------------------------------------------------------------------
+ * RCCL collectives of the frame-sharded long-clip mode (the reference has no
+ * counterpart: it cannot run clips longer than 24 frames, motion_module.py:237-255).  One
+ * communicator per process (= per GPU).  Rank 0 calls vsx_comm_unique_id and distributes the 128
+ * bytes out of band (torch.distributed store, MPI, a file); every rank then calls vsx_comm_init.
+ * librccl is opened with dlopen at the first call: libvsx.so has no link-time dependency on it.
+ * Collectives are asynchronous on `stream`; the caller orders them against compute with events.
+ *   vsx_allgather_kv:  kv_local [batch][elems_per_batch] fp16 (the K|V rows of this rank's frames,
+ *       elems_per_batch = f_local*hw*2C) -> kv_all [batch][nranks][elems_per_batch]: per batch item
+ *       the ranks' frame slabs in rank order = the [B, F_total, hw, 2C] tensor
+ *       vsx_temporal_attention_f16 reads with fk = F_total (K = columns [0,C), V = [C,2C), ldkv = 2C);
+ *   vsx_allgather_f32: fp32 GroupNorm partial sums (vsx_groupnorm_stats) of every rank, rank order;
+ *       vsx_groupnorm_apply then reduces them in a fixed order: identical statistics on every rank;
+ *   vsx_allreduce_gnstats: in-place fp32 sum over the ranks.
+ * ------------------------------------------------------------------------------------------ */
+int vsx_comm_unique_id(void* id128);
+int vsx_comm_init(int64_t rank, int64_t nranks, const void* id128);
+int64_t vsx_comm_size(void);
+int64_t vsx_comm_rank(void);
+int vsx_comm_destroy(void);
+int vsx_allgather_kv(const void* kv_local, void* kv_all, int64_t batch, int64_t elems_per_batch,
+                     vsx_stream_t stream);
+int vsx_allgather_f32(const float* local, float* all, int64_t count, vsx_stream_t stream);
+int vsx_allreduce_gnstats(float* partial, int64_t count, vsx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,13 +82,16 @@ def _frame_shard(rank, world):
     # --- temporal attention over ALL frames from all-gathered K/V ---
     q, k, v = torch.randn(B, T, HW, C), torch.randn(B, T, HW, C), torch.randn(B, T, HW, C)
     sl = slice(shard.frame_offset, shard.frame_offset + shard.local_frames)
-    kg, vg, fk = shard.kv_gather(k[:, sl].reshape(-1, HW, C), v[:, sl].reshape(-1, HW, C), B, shard.local_frames, HW)
-    assert fk == T and torch.equal(kg.view(B, T, HW, C), k) and torch.equal(vg.view(B, T, HW, C), v)
+    kv_local = torch.cat([k[:, sl], v[:, sl]], dim=-1).reshape(-1, 2 * C).contiguous()     # K | V columns
+    kv_all, fk = shard.kv_gather_finish(shard.kv_gather_start(kv_local, B, shard.local_frames, HW))
+    kg, vg = kv_all[:, :C], kv_all[:, C:]
+    assert fk == T and torch.equal(kg.reshape(B, T, HW, C), k) and torch.equal(vg.reshape(B, T, HW, C), v)
+    assert shard.bytes_gathered == (world - 1) * B * shard.local_frames * HW * 2 * C * 4
 
     def attn(qq, kk, vv):     # [B, f, HW, C] attention across the frame axis at every site
         s = torch.einsum('bfsc,bgsc->bsfg', qq, kk) / C ** 0.5
         return torch.einsum('bsfg,bgsc->bfsc', s.softmax(-1), vv)
-    at_err = (attn(q[:, sl], kg.view(B, T, HW, C), vg.view(B, T, HW, C)) - attn(q, k, v)[:, sl]).abs().max()
+    at_err = (attn(q[:, sl], kg.reshape(B, T, HW, C), vg.reshape(B, T, HW, C)) - attn(q, k, v)[:, sl]).abs().max()
     lat = torch.randn(1, 4, T, 3, 3)
     full = shard.gather_frames(shard.local_slice(lat))
     return (float(gn_err), float(at_err), bool(torch.equal(full, lat)), shard.frame_offset)

@@ -60,6 +60,106 @@ def _worker(rank, world, port, q):
         q.put(('error', rank, traceback.format_exc()))
 
 
+def _worker_full(rank, world, port, q):
+    """BASELINE.json configs[3] in one forward: the SD-1.5-width model, T = 64 (positional-encoding table extended to
+    64), B = 1, 32x32 latent, two ranks of 32 frames each sharing cuda:0 (fq = 32 local, fk = 64 gathered frames: the
+    long-clip MFMA temporal kernel), against the single-device fp32 oracle on the full 64-frame clip."""
+    import sys
+    import traceback
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from videoswap_amd.distributed import FrameShard
+        from videoswap_amd.synthetic import synth_weights_
+        from videoswap_amd.unet import SD15_UNET_CONFIG, AnimateDiffUNet3DModel, inference_kwargs
+        frames, hw = 64, 32
+        cfg = dict(SD15_UNET_CONFIG)
+        cfg.update(inference_kwargs(max_len=frames))
+        with torch.device('cuda'):
+            prod = AnimateDiffUNet3DModel(**cfg)
+        prod = synth_weights_(prod, seed=1234).half().eval()
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(1, 4, frames, hw, hw, generator=g)
+        txt = torch.randn(1, 77, 768, generator=g)
+        shard = FrameShard(frames)
+        shard.install(prod)
+        with torch.no_grad():
+            local = prod(shard.local_slice(x).half().cuda(), 301, txt.half().cuda()).sample
+            full = shard.gather_frames(local).float().cpu()
+        gathered = shard.bytes_gathered
+        FrameShard.uninstall(prod)
+        out = None
+        if rank == 0:
+            from oracle import unet3d
+            ora = unet3d.AnimateDiffUNet3DModel(**unet3d.full_config(max_len=frames)).eval()
+            ora.load_state_dict({k: v.float().cpu() for k, v in prod.state_dict().items()}, strict=True)
+            ora = ora.to('cuda')
+            with torch.no_grad():
+                ref = ora(x.cuda(), torch.tensor(301), txt.cuda()).sample.float().cpu()
+                ref16 = ora.half()(x.half().cuda(), torch.tensor(301), txt.half().cuda()).sample.float().cpu()
+            out = (float((full - ref).norm() / ref.norm()), float((ref16 - ref).norm() / ref.norm()), gathered)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(('ok', rank, out))
+    except Exception:  # pragma: no cover
+        q.put(('error', rank, traceback.format_exc()))
+
+
+def _spawn(worker, world=2, timeout=600):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get() for _ in range(world)]
+    for p in procs:
+        p.join(timeout)
+    errs = [r for r in results if r[0] != 'ok']
+    assert not errs, errs[0][2]
+    return [r[2] for r in results if r[1] == 0][0]
+
+
+def test_long_clip_64_frames_full_width():
+    err, e16, gathered = _spawn(_worker_full)
+    print(f'64-frame clip, 2 x 32 frames, SD-1.5 width: rel-L2 {err:.3e} (fp16-storage oracle {e16:.3e}); '
+          f'{gathered / 1e6:.1f} MB of K|V received per rank and forward')
+    assert err <= 2 * e16
+    assert gathered > 0
+
+
+def test_rccl_entry_points_single_rank():
+    """vsx_comm_* / vsx_allgather_kv / vsx_allgather_f32 / vsx_allreduce_gnstats through the C ABI with a one-rank
+    communicator (the only RCCL topology a 1-GPU box offers: RCCL refuses two ranks on one device): librccl is
+    dlopen'ed, the communicator comes up, the collectives run on the given stream and reproduce their input."""
+    import ctypes
+    from videoswap_amd import _lib, ops
+    lib = _lib.load()
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(lib.vsx_comm_unique_id(uid), 'vsx_comm_unique_id')
+    assert any(uid.raw)
+    _lib.check(lib.vsx_comm_init(0, 1, uid), 'vsx_comm_init')
+    try:
+        assert lib.vsx_comm_size() == 1 and lib.vsx_comm_rank() == 0
+        kv = torch.randn(2, 4 * 16 * 128, device='cuda', dtype=torch.float16)
+        out = torch.zeros(2, 1, 4 * 16 * 128, device='cuda', dtype=torch.float16)
+        _lib.check(lib.vsx_allgather_kv(ops._p(kv), ops._p(out), 2, kv.shape[1], ops._stream()), 'vsx_allgather_kv')
+        part = torch.randn(2, 3, 32, 2, device='cuda')
+        allp = torch.zeros_like(part)
+        _lib.check(lib.vsx_allgather_f32(ops._p(part), ops._p(allp), part.numel(), ops._stream()), 'vsx_allgather_f32')
+        red = part.clone()
+        _lib.check(lib.vsx_allreduce_gnstats(ops._p(red), red.numel(), ops._stream()), 'vsx_allreduce_gnstats')
+        torch.cuda.synchronize()
+        assert torch.equal(out.view_as(kv), kv) and torch.equal(allp, part) and torch.equal(red, part)
+    finally:
+        _lib.check(lib.vsx_comm_destroy(), 'vsx_comm_destroy')
+    assert lib.vsx_comm_size() == 0
+
+
 def test_frame_sharded_unet_matches_full_clip_oracle():
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')

@@ -76,6 +76,14 @@ PROTOTYPES = {
     'vsx_adapter_scatter': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_int64, c_float, c_float, c_void_p]),
     'vsx_prof_enable': (c_int, [c_int64, c_int64]),
+    'vsx_comm_unique_id': (c_int, [c_void_p]),
+    'vsx_comm_init': (c_int, [c_int64, c_int64, c_void_p]),
+    'vsx_comm_size': (c_int64, []),
+    'vsx_comm_rank': (c_int64, []),
+    'vsx_comm_destroy': (c_int, []),
+    'vsx_allgather_kv': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'vsx_allgather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'vsx_allreduce_gnstats': (c_int, [c_void_p, c_int64, c_void_p]),
     'vsx_prof_pause': (c_int, [c_int64]),
     'vsx_prof_collect': (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
 }

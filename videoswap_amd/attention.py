@@ -293,14 +293,23 @@ class VanillaAttentionProcessor(nn.Module):
         if self.pos_encoder is not None and not pe_applied:
             pe = self.pe_table()[self.frame_offset:self.frame_offset + frames].to(x.dtype)
             x = (x.view(b, frames, hw, c) + pe[None, :, None, :]).view(bf, hw, c)
-        if attn.to_q.bias is None and attn.to_k.bias is None and attn.to_v.bias is None:
+        nobias = attn.to_q.bias is None and attn.to_k.bias is None and attn.to_v.bias is None
+        fk = frames
+        if self.kv_gather is not None:
+            # frame-sharded long clip: K|V of the local frames first (one GEMM, N = 2C), their all-gather over the
+            # frame axis goes in flight, the q projection runs behind it
+            if nobias:
+                kv = ops.linear(x, attn.fused_weight(('to_k', 'to_v'))).view(-1, 2 * c)
+            else:
+                kv = torch.cat([attn.to_k(x).view(-1, c), attn.to_v(x).view(-1, c)], dim=1)
+            handle = self.kv_gather.kv_gather_start(kv, b, frames, hw)
+            q = attn.to_q(x).view(-1, c)
+            kv_all, fk = self.kv_gather.kv_gather_finish(handle)
+            k, v = kv_all[:, :c], kv_all[:, c:]
+        elif nobias:
             qkv = ops.linear(x, attn.fused_weight(('to_q', 'to_k', 'to_v'))).view(-1, 3 * c)   # one GEMM, N = 3C
             q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
         else:
             q, k, v = attn.to_q(x).view(-1, c), attn.to_k(x).view(-1, c), attn.to_v(x).view(-1, c)
-        fk = frames
-        if self.kv_gather is not None:
-            k, v, fk = self.kv_gather(k.contiguous().view(bf, hw, c), v.contiguous().view(bf, hw, c), b, frames, hw)
-            k, v = k.view(-1, c), v.view(-1, c)
         o = ops.temporal_attention(q, k, v, b, frames, fk, hw, attn.heads, attn.scale).view(bf, hw, c)
         return attn.to_out[0](o, residual=residual)

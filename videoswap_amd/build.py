@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIB = os.path.join(LIBDIR, 'libvsx.so')
-SOURCES = ['api.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip']
+SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-Wall', '-Wno-unused-function', '-Wno-division-by-zero',
@@ -80,7 +80,7 @@ def build(force=False, verbose=True):
         raise RuntimeError(f'{HIPCC} not found: cannot build libvsx.so')
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(lambda src: _compile(src, digest), SOURCES))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')

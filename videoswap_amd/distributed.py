@@ -6,9 +6,10 @@ RCCL over xGMI on ROCm; "gloo" is used by the CPU tests and by single-GPU emulat
 
 2. Frame-sharded long-clip mode (configs[3]): rank r owns frames [r*T/P, (r+1)*T/P) of the [B, F, H, W, C] activations;
    weights are replicated.  Everything in the UNet is per-frame local except two couplings, which `FrameShard` wires in:
-     * temporal attention attends across ALL frames: K and V of the local frames are all-gathered over the frame axis
-       right after their projections (`kv_gather`, consumed by `vsx_temporal_attention_f16` with fq local / fk global
-       frames); the positional encoding uses the GLOBAL frame index (`frame_offset`);
+     * temporal attention attends across ALL frames: the fused K|V projection of the local frames is all-gathered over
+       the frame axis into one [B, F_total, hw, 2C] buffer (`kv_gather_start/finish`: one collective per batch item,
+       in flight while the q projection runs), consumed by `vsx_temporal_attention_f16` with fq local / fk global
+       frames (its long-clip MFMA kernel); the positional encoding uses the GLOBAL frame index (`frame_offset`);
      * the reference's ResnetBlock3D / conv_norm_out GroupNorm pools statistics over frames (resnet.py:166,177;
        unet.py:474): the fp32 partial sums produced by `vsx_groupnorm_stats` are all-gathered (`gn_hook`) and reduced
        in rank order by `vsx_groupnorm_apply`, so every rank computes bit-identical statistics.
@@ -37,24 +38,53 @@ def _coll_device():
     return torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
 
 
-def _all_gather(t, group=None):
-    """all-gather of equal-shape tensors -> list in rank order.  With gloo (CPU tests, single-GPU emulation) GPU
-    tensors are staged through the host."""
-    world = dist.get_world_size(group)
+def _all_gather_into(out, t, group=None):
+    """`out` [world, *t.shape] <- every rank's `t`, in rank order: ONE collective into a preallocated tensor (no list
+    of parts, no torch.cat).  With gloo (CPU tests, single-GPU emulation) GPU tensors are staged through the host."""
+    assert out.is_contiguous() and out.numel() == dist.get_world_size(group) * t.numel()
     if dist.get_backend(group) == 'nccl' or not t.is_cuda:
-        out = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(out, t.contiguous(), group=group)
+        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=group)
         return out
-    host = t.detach().cpu().contiguous()
-    out = [torch.empty_like(host) for _ in range(world)]
-    dist.all_gather(out, host, group=group)
-    return [o.to(t.device) for o in out]
+    host_out = torch.empty(out.numel(), dtype=out.dtype)
+    dist.all_gather_into_tensor(host_out, t.detach().cpu().contiguous().view(-1), group=group)
+    out.view(-1).copy_(host_out)
+    return out
+
+
+class RcclComm:
+    """The library's own RCCL communicator (include/vsx.h: vsx_comm_*): one per process.  The 128-byte unique id is
+    created by rank 0 and broadcast through torch.distributed's store-backed object collective (out-of-band: any
+    rendezvous would do)."""
+
+    def __init__(self, group=None):
+        import ctypes
+        from . import _lib
+        self.lib = _lib.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(self.lib.vsx_comm_unique_id(buf), 'vsx_comm_unique_id')
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        uid = ctypes.create_string_buffer(box[0], 128)
+        _lib.check(self.lib.vsx_comm_init(self.rank, self.world, uid), 'vsx_comm_init')
+        self.stream = torch.cuda.Stream()        # collectives run beside the compute stream
+
+    def close(self):
+        from . import _lib
+        _lib.check(self.lib.vsx_comm_destroy(), 'vsx_comm_destroy')
 
 
 class FrameShard:
-    """Frame-axis sharding of one clip over the ranks of `group` (see module docstring)."""
+    """Frame-axis sharding of one clip over the ranks of `group` (see module docstring).
 
-    def __init__(self, total_frames, group=None):
+    `backend='rccl'` routes the two exchanges through the library's C-ABI collectives (vsx_allgather_kv /
+    vsx_allgather_f32) on a side stream: the K|V all-gather of a temporal attention overlaps with its q projection.
+    `backend='torch'` uses torch.distributed (`all_gather_into_tensor`; gloo in the CPU tests and the single-GPU
+    emulation).  Either way each exchange is ONE collective per batch item into a preallocated buffer laid out as the
+    attention kernel reads it ([B, F_total, hw, 2C]: K = columns [0, C), V = [C, 2C))."""
+
+    def __init__(self, total_frames, group=None, backend=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -63,22 +93,64 @@ class FrameShard:
         self.total_frames = total_frames
         self.local_frames = total_frames // self.world
         self.frame_offset = self.rank * self.local_frames
+        if backend is None:
+            backend = 'rccl' if dist.get_backend(group) == 'nccl' else 'torch'
+        self.backend = backend
+        self.comm = RcclComm(group) if backend == 'rccl' else None
+        self.bytes_gathered = 0                  # K|V bytes received per forward (DESIGN.md §6)
 
-    # ---- hooks -------------------------------------------------------------------------------------------------
+    # ---- GroupNorm partial sums ----------------------------------------------------------------------------------
     def gn_hook(self, partial):
         """[B, nchunks, groups, 2] fp32 partial sums of the local frames -> [B, world*nchunks, groups, 2] of all
-        frames, concatenated in rank order (deterministic reduction order on every rank)."""
-        return torch.cat(_all_gather(partial, self.group), dim=1).contiguous()
+        frames in rank order (every rank then reduces them in the same fixed order: bit-identical statistics)."""
+        b, nchunks, groups, two = partial.shape
+        gathered = torch.empty(self.world, b, nchunks, groups, two, dtype=partial.dtype, device=partial.device)
+        if self.comm is not None:
+            from . import _lib, ops
+            part = partial.contiguous()
+            _lib.check(self.comm.lib.vsx_allgather_f32(ops._p(part), ops._p(gathered), part.numel(), ops._stream()),
+                       'vsx_allgather_f32')
+        else:
+            _all_gather_into(gathered, partial, self.group)
+        return gathered.permute(1, 0, 2, 3, 4).reshape(b, self.world * nchunks, groups, two).contiguous()
 
-    def kv_gather(self, k, v, b, frames, hw):
-        """k, v [b*frames, hw, C] of the local frames -> [b*total_frames, hw, C] (frame-major per batch) and the
-        global frame count."""
-        c = k.shape[-1]
+    # ---- temporal K|V ----------------------------------------------------------------------------------------------
+    def kv_gather_start(self, kv, b, frames, hw):
+        """kv [b*frames*hw, 2C] (this rank's frames, K | V columns) -> handle; the collective is in flight when this
+        returns (rccl backend) so that the caller can launch the q projection behind it."""
+        c2 = kv.shape[-1]
+        per_batch = frames * hw * c2
+        out = torch.empty(b, self.world, per_batch, dtype=kv.dtype, device=kv.device)
+        self.bytes_gathered += (self.world - 1) * b * per_batch * kv.element_size()
+        if self.comm is not None:
+            from . import _lib, ops
+            cur = torch.cuda.current_stream()
+            side = self.comm.stream
+            side.wait_stream(cur)                                # kv (and `out`'s allocation) are ready
+            kv.record_stream(side)
+            out.record_stream(side)
+            import ctypes
+            with torch.cuda.stream(side):
+                _lib.check(self.comm.lib.vsx_allgather_kv(ops._p(kv), ops._p(out), b, per_batch,
+                                                          ctypes.c_void_p(side.cuda_stream)), 'vsx_allgather_kv')
+                done = torch.cuda.Event()
+                done.record(side)
+            return out, done, c2
+        if b == 1:
+            _all_gather_into(out.view(self.world, per_batch), kv.reshape(per_batch), self.group)
+        else:                                    # the frame axis is not outermost: one collective per batch item
+            for i in range(b):
+                part = torch.empty(self.world, per_batch, dtype=kv.dtype, device=kv.device)
+                _all_gather_into(part, kv.view(b, per_batch)[i], self.group)
+                out[i] = part
+        return out, None, c2
 
-        def gather(t):
-            parts = _all_gather(t.view(b, frames, hw, c), self.group)          # world x [b, f_local, hw, c]
-            return torch.cat(parts, dim=1).reshape(b * self.total_frames, hw, c).contiguous()
-        return gather(k), gather(v), self.total_frames
+    def kv_gather_finish(self, handle):
+        """-> (kv_all [b*F_total*hw, 2C], F_total)"""
+        out, done, c2 = handle
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+        return out.view(-1, c2), self.total_frames
 
     # ---- wiring ------------------------------------------------------------------------------------------------
     def install(self, unet):
@@ -88,7 +160,7 @@ class FrameShard:
         for m in unet.modules():
             proc = getattr(m, 'processor', None)
             if isinstance(proc, VanillaAttentionProcessor):
-                proc.kv_gather = self.kv_gather
+                proc.kv_gather = self
                 proc.frame_offset = self.frame_offset
                 if proc.pos_encoder is not None and proc.pos_encoder.pe.shape[1] < self.total_frames:
                     raise ValueError('temporal_position_encoding_max_len is smaller than the clip: build the UNet with '
@@ -111,4 +183,8 @@ class FrameShard:
 
     def gather_frames(self, latents_local):
         """this rank's [B, C, f, H, W] -> full clip on every rank"""
-        return torch.cat(_all_gather(latents_local, self.group), dim=2)
+        x = latents_local.contiguous()
+        parts = torch.empty(self.world, *x.shape, dtype=x.dtype, device=x.device)
+        _all_gather_into(parts, x, self.group)
+        b, c, f, h, w = x.shape
+        return parts.permute(1, 2, 0, 3, 4, 5).reshape(b, c, self.world * f, h, w).contiguous()
