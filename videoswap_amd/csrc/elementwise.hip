@@ -97,22 +97,35 @@ __global__ void adapter_scatter_kernel(const float* __restrict__ tracks, const i
         const float x = (float)(half_t)((float)(half_t)px / rate), y = (float)(half_t)((float)(half_t)py / rate);
         int x1 = (int)x, y1 = (int)y;
         int x2 = x1 + 1, y2 = y1 + 1;
-        const float xf = x - (float)x1, yf = y - (float)y1;
+        const float xf = (float)(half_t)(x - (float)x1), yf = (float)(half_t)(y - (float)y1);
         x1 = max(min(x1, w - 1), 0); x2 = max(min(x2, w - 1), 0);
         y1 = max(min(y1, h - 1), 0); y2 = max(min(y2, h - 1), 0);
-        const float wgt[4] = {(1.f - xf) * (1.f - yf), xf * (1.f - yf), (1.f - xf) * yf, xf * yf};
+        // the reference's weights are products of 0-dim fp16 tensors: every intermediate is rounded to fp16
+        const float xm = (float)(half_t)(1.f - xf), ym = (float)(half_t)(1.f - yf);
+        const float wgt[4] = {(float)(half_t)(xm * ym), (float)(half_t)(xf * ym), (float)(half_t)(xm * yf),
+                              (float)(half_t)(xf * yf)};
         const int xs[4] = {x1, x2, x1, x2};
         const int ys[4] = {y1, y1, y2, y2};
         for (int k = 0; k < 4; ++k) {
             half_t* dst = out + (((long)f * h + ys[k]) * w + xs[k]) * C;
             for (int c = threadIdx.x; c < C; c += blockDim.x) {
-                const float v = (float)feat[(long)pt * C + c] * out_scale;
+                const float v = (float)feat[(long)pt * C + c];
                 // reference rounds (value*w) to fp16, then the += rounds again
                 const half_t add = (half_t)(v * wgt[k]);
                 dst[c] = (half_t)((float)dst[c] + (float)add);
             }
             // same threads own the same channels for every corner/point: no barrier needed
         }
+    }
+    // t2i_guidance_scale multiplies the FINISHED map (pipeline_videoswap.py:545-546), one more fp16 rounding; a thread
+    // owns the same channels of every pixel, so it only touches values it accumulated itself
+    if (out_scale != 1.0f) {
+        half_t* base = out + (long)f * h * w * C;
+        for (long px = 0; px < (long)h * w; ++px)
+            for (int c = threadIdx.x; c < C; c += blockDim.x) {
+                const half_t v = base[px * C + c];
+                if ((float)v != 0.f) base[px * C + c] = (half_t)((float)v * out_scale);
+            }
     }
 }
 

@@ -58,7 +58,7 @@ class FlopCounter:
         cls.enabled, cls.gemm, cls.attention = enabled, 0.0, 0.0
 
 
-_split_ws = {}      # device -> grow-only fp32 scratch for split-K partial sums (stream-ordered reuse)
+_split_ws = {}      # (device, stream) -> grow-only fp32 scratch for split-K partial sums (stream-ordered reuse)
 
 
 def gemm(desc):
@@ -67,14 +67,17 @@ def gemm(desc):
         FlopCounter.gemm += 2.0 * desc.M * cols * desc.K * desc.batch0 * desc.batch1
     lib = _lib.load()
     need = lib.vsx_gemm_workspace(ctypes.byref(desc)) if (desc.M <= 20480 and desc.K >= 768) else 0
+    stream = _stream()
     if need > 0:
-        dev = torch.cuda.current_device()
-        ws = _split_ws.get(dev)
+        # one scratch buffer per (device, stream): launches on one stream are ordered, two streams (or a graph capture
+        # next to eager work) must not share partial sums
+        key = (torch.cuda.current_device(), stream.value)
+        ws = _split_ws.get(key)
         if ws is None or ws.numel() * 4 < need:
-            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=f'cuda:{dev}')
-            _split_ws[dev] = ws
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=f'cuda:{key[0]}')
+            _split_ws[key] = ws
         desc.workspace, desc.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    check(lib.vsx_gemm_f16(ctypes.byref(desc), _stream()), 'vsx_gemm_f16')
+    check(lib.vsx_gemm_f16(ctypes.byref(desc), stream), 'vsx_gemm_f16')
 
 
 def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
