@@ -23,16 +23,11 @@ timeout 400 python bench.py --steps 3 --warmup 1 > $O/${TAG}_bench_graphs.log 2>
 tail -n 1 $O/${TAG}_bench_graphs.log | cut -c1-260
 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graphs > $O/${TAG}_bench_eager.log 2>&1
 tail -n 1 $O/${TAG}_bench_eager.log | cut -c1-260
-VSX_GEMM_PP=0 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graphs > $O/${TAG}_bench_tile_eager.log 2>&1
-tail -n 1 $O/${TAG}_bench_tile_eager.log | cut -c1-260
 # kernel trace (eager: per-kernel names; same command as round 1) and of the graph-replay mode
 ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_eager -o r02 -- python $R/bench.py --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --no-graphs --prof-samples 0 > $O/${TAG}_prof_eager.log 2>&1 )
 DB=$(find $O/${TAG}_prof_eager -name '*.db' | head -n 1)
 [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $O/${TAG}_kernel_stats_eager.txt 2>&1
-( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_graphs -o r02 -- python $R/bench.py --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --prof-samples 0 > $O/${TAG}_prof_graphs.log 2>&1 )
-DB=$(find $O/${TAG}_prof_graphs -name '*.db' | head -n 1)
-[ -n "$DB" ] && python tools/rocpd_summary.py $DB > $O/${TAG}_kernel_stats_graphs.txt 2>&1
-find $O/${TAG}_prof_eager $O/${TAG}_prof_graphs -type f -size +4M -delete 2>/dev/null
+find $O/${TAG}_prof_eager -type f -size +4M -delete 2>/dev/null
 tail -n 3 $O/${TAG}_kernel_stats_eager.txt | cut -c1-200
 if [ "${SKIP_PMC:-0}" != "1" ]; then
   bash tools/pmc_sq.sh ${TAG}_pmc_sq
