@@ -44,9 +44,11 @@ def parse():
     # hipEvent pairs around every 7th vsx_gemm_f16 launch (7 is coprime with the ~470 GEMM launches of a UNet call, so
     # every shape is sampled over the 100 calls of a clip); bracketing EVERY launch costs 5 % of the loop
     ap.add_argument('--prof-stride', type=int, default=7)
-    ap.add_argument('--no-graphs', action='store_true',
-                    help='launch every kernel eagerly (default: HIP-graph replay of the UNet forward; every '
-                         '--prof-stride-th UNet call stays eager and carries the hipEvent brackets)')
+    ap.add_argument('--graphs', action='store_true',
+                    help='HIP-graph replay of the UNet forward (every --prof-stride-th UNet call stays eager and '
+                         'carries the hipEvent brackets).  Off by default: the replay path has not been timed on '
+                         'hardware yet (round 2 ran out of GPU minutes), so the headline number is the eager one')
+    ap.add_argument('--no-graphs', action='store_true', help='(default) launch every kernel eagerly')
     return ap.parse_args()
 
 
@@ -145,7 +147,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    graphs = not args.no_graphs
+    graphs = args.graphs and not args.no_graphs
     if graphs:
         # graph replay for the UNet forward; every prof_stride-th call runs eagerly and is the one whose GEMM launches
         # are bracketed by hipEvents (ALL of them: same 1/stride sampling fraction as the eager mode's every-7th-launch)

@@ -95,9 +95,9 @@ def _worker_full(rank, world, port, q):
         out = None
         if rank == 0:
             from oracle import unet3d
-            ora = unet3d.AnimateDiffUNet3DModel(**unet3d.full_config(max_len=frames)).eval()
-            ora.load_state_dict({k: v.float().cpu() for k, v in prod.state_dict().items()}, strict=True)
-            ora = ora.to('cuda')
+            with torch.device('cuda'):
+                ora = unet3d.AnimateDiffUNet3DModel(**unet3d.full_config(max_len=frames)).eval()
+            ora.load_state_dict({k: v.float() for k, v in prod.state_dict().items()}, strict=True)
             with torch.no_grad():
                 ref = ora(x.cuda(), torch.tensor(301), txt.cuda()).sample.float().cpu()
                 ref16 = ora.half()(x.half().cuda(), torch.tensor(301), txt.half().cuda()).sample.float().cpu()

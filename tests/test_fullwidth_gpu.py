@@ -45,20 +45,22 @@ def _record(name, **kw):
 
 @pytest.fixture(scope='module')
 def models():
+    """Everything is built ON the device (seeded generator of videoswap_amd.synthetic: seconds instead of the minute
+    a CPU initialisation of 860 M parameters takes); the oracle copies receive the product's fp16-exact weights."""
     from oracle import unet3d
+    from videoswap_amd.synthetic import synth_weights_
     from videoswap_amd.unet import AnimateDiffUNet3DModel
     cfg = unet3d.full_config()
     t0 = time.time()
-    ora = unet3d.AnimateDiffUNet3DModel(**cfg).eval()
-    unet3d.synth_weights_(ora, seed=1234)
-    prod = AnimateDiffUNet3DModel(**cfg).eval()
-    missing, unexpected = prod.load_state_dict(ora.state_dict(), strict=True)
+    with torch.device('cuda'):
+        prod = AnimateDiffUNet3DModel(**cfg)
+        ora_dev = unet3d.AnimateDiffUNet3DModel(**cfg).eval()            # fp32 oracle, device-placed
+    prod = synth_weights_(prod, seed=1234).half().eval()
+    missing, unexpected = ora_dev.load_state_dict({k: v.float() for k, v in prod.state_dict().items()}, strict=True)
     assert not missing and not unexpected
-    prod = prod.to('cuda', torch.float16)
-    ora_dev = copy.deepcopy(ora).to('cuda')                 # fp32 oracle, device-placed
-    ora_h = copy.deepcopy(ora).to('cuda', torch.float16)    # fp16-storage oracle: the error yardstick
+    ora_h = copy.deepcopy(ora_dev).half()                                # fp16-storage oracle: the error yardstick
     print(f'[fullwidth] models built in {time.time() - t0:.1f} s')
-    return cfg, ora, ora_dev, ora_h, prod
+    return cfg, None, ora_dev, ora_h, prod
 
 
 def _inputs(B, T, H, W, seed, layers=None):
@@ -95,7 +97,8 @@ def _check(name, prod_out, ref, half_out, extra=None):
 def test_forward_vs_host_oracle(models):
     """(1) B = 1, T = 2, 64x64 with the fp32 oracle on the HOST cores (~40 s on the 128-core box): anchors the
     device-placed fp32 oracle the larger cases use, and checks the product against the host oracle directly."""
-    cfg, ora, ora_dev, ora_h, prod = models
+    cfg, _, ora_dev, ora_h, prod = models
+    ora = copy.deepcopy(ora_dev).cpu()
     x, txt = _inputs(1, 2, 64, 64, seed=101)
     t0 = time.time()
     torch.set_num_threads(os.cpu_count() or 1)

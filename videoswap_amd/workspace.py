@@ -117,10 +117,14 @@ def write_synthetic_workspace(root, opt, width='tiny', seed=1234, total_frames=N
     os.makedirs(os.path.join(sd_dir, 'unet'), exist_ok=True)
     with open(os.path.join(sd_dir, 'unet', 'config.json'), 'w') as f:
         json.dump(unet_cfg, f, indent=1)
-    unet = AnimateDiffUNet3DModel(block_out_channels=tuple(boc), cross_attention_dim=text_dim, sample_size=64,
-                                  **inference_kwargs(max_len=24))
+    # build and fill the big model on the GPU when there is one (a CPU initialisation of the SD-1.5 width takes a minute)
+    dev = 'cuda' if (not tiny and torch.cuda.is_available()) else 'cpu'
+    with torch.device(dev):
+        unet = AnimateDiffUNet3DModel(block_out_channels=tuple(boc), cross_attention_dim=text_dim, sample_size=64,
+                                      **inference_kwargs(max_len=24))
     synth_weights_(unet, seed=seed)
-    full_sd = unet.state_dict()
+    full_sd = {k: v.cpu() for k, v in unet.state_dict().items()}
+    del unet
     _save({k: v.to(store).contiguous() for k, v in full_sd.items() if 'motion_modules' not in k},
           os.path.join(sd_dir, 'unet', 'diffusion_pytorch_model.bin'))
     mm_path = opt['models']['unet'].get('motion_module_path')
