@@ -6,7 +6,8 @@
 Reported per kernel name (template instantiation): dispatches, and for every counter its sum over the dispatches;
 derived: MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES-normalised CU cycles) as the guide defines it
 (SQ_VALU_MFMA_BUSY_CYCLES counts cycles = 32 x N_mfma(32x32x16) per SIMD; GRBM_GUI_ACTIVE = wall cycles of the
-dispatch), i.e. mfma_util = MFMA_BUSY / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)."""
+dispatch, SUMMED over the 8 XCDs by rocprofv3), i.e. mfma_util = MFMA_BUSY / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs);
+cross-check of the XCD factor: the conv kernel reads 0.52 at 1.2 PF/s and ~1.95 GHz (profiles/r02_pmc_sq.txt)."""
 import csv
 import glob
 import os
@@ -44,7 +45,7 @@ def main(root):
         line = f'{k:80s} n={n:5d}'
         gui = s.get('GRBM_GUI_ACTIVE', 0.0)
         if gui and 'SQ_VALU_MFMA_BUSY_CYCLES' in s:
-            line += f'  mfma_util={s["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024):6.3f}'
+            line += f'  mfma_util={s["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 128):6.3f}'
         wc = s.get('SQ_WAVE_CYCLES', 0.0)
         if wc:
             for c, tag in (('SQ_WAIT_INST_ANY', 'issue_stall'), ('SQ_WAIT_ANY', 'parked'),
