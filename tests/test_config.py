@@ -110,6 +110,9 @@ def test_config1_product_matches_oracle_flow(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get('VSX_HEAVY_TESTS') != '1',
+                    reason='writes and reloads 2.5 GB of SD-1.5-shaped checkpoints (minutes): VSX_HEAVY_TESTS=1; passed '
+                           'in round-2 GPU run 4 (gpurun_out/r02d_pytest.log)')
 def test_config1_full_width_plumbing(tmp_path):
     """BASELINE.json configs[0] at the SD-1.5 width: checkpoints in the real shapes, T = 4, 2 + 2 steps."""
     opt, info = _prepare(tmp_path, 'full', {'mixed_precision': 'fp16'})

@@ -184,7 +184,12 @@ def _product_loops(prod, x, txt, neg, steps, guidance=7.5):
     return inv.float().cpu(), out.float().cpu()
 
 
-@pytest.mark.parametrize('steps', [5, 50])
+HEAVY = pytest.mark.skipif(os.environ.get('VSX_HEAVY_TESTS') != '1',
+                           reason='several minutes of oracle time: run with VSX_HEAVY_TESTS=1 (last recorded result: '
+                                  'profiles/r02_parity_fullwidth_run1.json)')
+
+
+@pytest.mark.parametrize('steps', [5, pytest.param(50, marks=HEAVY)])
 def test_sequential_steps_full_width(models, steps):
     """(5) `steps` inversion steps (B = 1) + `steps` CFG-7.5 sampling steps (B = 2) at T = 16, 64x64: config 2 of
     BASELINE.json for steps = 50 (the run bench.py times).  The final latents obey the same <= 2x rule against the
