@@ -85,7 +85,8 @@ def cpu_baseline(frames_sample=2, latent=64, repeats=2):
     CPU work as the bench contract asks: a full T=16 step pair is ~5 min on 128 cores)."""
     from oracle import unet3d
     torch.manual_seed(0)
-    torch.set_num_threads(os.cpu_count() or 1)
+    # PyTorch's default intra-op thread count (= physical cores).  Forcing os.cpu_count() (the SMT thread count) made
+    # the same forward 3.5x SLOWER on the 128-core box (round-2 run 1: 41 s instead of 11.8 s for T = 2)
     threads = torch.get_num_threads()
     model = unet3d.AnimateDiffUNet3DModel(**unet3d.full_config()).eval()
     for n, p in model.named_parameters():           # proj_out is zero-initialised: make the temporal path live

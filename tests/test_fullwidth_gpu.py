@@ -101,7 +101,6 @@ def test_forward_vs_host_oracle(models):
     ora = copy.deepcopy(ora_dev).cpu()
     x, txt = _inputs(1, 2, 64, 64, seed=101)
     t0 = time.time()
-    torch.set_num_threads(os.cpu_count() or 1)
     ref = _fwd(ora, x, 481, txt)
     host_s = time.time() - t0
     ref_dev = _fwd(ora_dev, x, 481, txt)

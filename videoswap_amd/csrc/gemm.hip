@@ -1046,13 +1046,9 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     const bool pp_ok = pp != 0 && wide && nbatch == 1 && (splits <= 1 || pp >= 2) && !force_tile() && pp_supported(p);
     // option gemm_pp: 0 never, 1 automatic (thresholds from tools/gemm_ab.py: profiles/r02_gemm_ab_*.txt), 2 = 256-row
     // tiles wherever >= 64 of them exist (else 128-row), 3 = 128-row tiles wherever >= 32 exist
-    // automatic rule (profiles/r02_gemm_ab_b{1,2}.txt): 256-row tiles from 3/4 of a wave of workgroups up (192 tiles);
-    // 128-row tiles for the plain GEMMs that have about one such tile per CU (the 640 / 1280-wide projections at
-    // M = 16 384 / 8 192: 8-12 % over the tile kernels; convolutions tie there and stay on the tile kernels)
-    if (pp_ok && pp != 3 && (blocks(256, 320) >= 192 || (pp == 2 && blocks(256, 320) >= 64))) {
+    if (pp_ok && pp != 3 && (blocks(256, 320) >= 200 || (pp == 2 && blocks(256, 320) >= 64))) {
         rc = launch_pp(p, 256, stream);
-    } else if (pp_ok && ((pp == 1 && p.a_mode == 0 && splits <= 1 && blocks(128, 320) >= 240) ||
-                         (pp >= 2 && blocks(128, 320) >= 32))) {
+    } else if (pp_ok && pp >= 2 && blocks(128, 320) >= 32) {
         rc = launch_pp(p, 128, stream);
     } else if (force_tile() && wide) {
         p.ws = (float*)d->workspace;
