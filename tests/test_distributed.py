@@ -102,3 +102,51 @@ def test_frame_shard_exchange_steps():
     for gn_err, at_err, ok, off in res:
         assert gn_err < 1e-4 and at_err < 1e-5 and ok
     assert sorted(r[3] for r in res) == [0, 4]
+
+
+def _site_shard(rank, world):
+    """exchange='sites': frames -> sites -> frames is the identity, the site layout holds every frame of this rank's
+    sites in global frame order, and temporal attention computed on it equals the full-clip result."""
+    from videoswap_amd.distributed import FrameShard
+    torch.manual_seed(0)
+    B, T, HW, C = 2, 8, 3 * world, 16
+    shard = FrameShard(T, exchange='sites')
+    x = torch.randn(B, T, HW, C).half()
+    sl = slice(shard.frame_offset, shard.frame_offset + shard.local_frames)
+    mine = x[:, sl].reshape(-1, C).contiguous()
+    hl = HW // world
+    ys = shard.to_sites(mine, B, HW)
+    want = x[:, :, rank * hl:(rank + 1) * hl].reshape(-1, C)            # all frames, my sites
+    layout_ok = torch.equal(ys, want)
+    moved = shard.bytes_gathered
+    back = shard.to_frames(ys, B, HW)
+    round_trip = torch.equal(back, mine)
+    # temporal attention on the site layout == the full computation restricted to my sites
+    q, k, v = (torch.randn(B, T, HW, C) for _ in range(3))
+
+    def attn(qq, kk, vv):
+        s = torch.einsum('bfsc,bgsc->bsfg', qq, kk) / C ** 0.5
+        return torch.einsum('bsfg,bgsc->bfsc', s.softmax(-1), vv)
+
+    def sites(t):
+        return shard.to_sites(t[:, sl].reshape(-1, C).contiguous(), B, HW).view(B, T, hl, C)
+    o_sites = attn(sites(q), sites(k), sites(v))                         # [B, T, hl, C]
+    o_frames = shard.to_frames(o_sites.reshape(-1, C).contiguous(), B, HW).view(B, shard.local_frames, HW, C)
+    at_err = (o_frames - attn(q, k, v)[:, sl]).abs().max()
+    try:
+        FrameShard(T, exchange='sites').sites_per_rank(7)
+        refused = False
+    except ValueError:
+        refused = True
+    return (layout_ok, round_trip, float(at_err), moved, refused)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_site_reshard_exchange(world):
+    res = _run(_site_shard, world)
+    B, T, HW, C = 2, 8, 3 * world, 16
+    for layout_ok, round_trip, at_err, moved, refused in res:
+        assert layout_ok and round_trip and refused
+        assert at_err < 1e-5
+        # one all-to-all moves (world-1)/world of the LOCAL activation: fp16, B x T/world frames x HW/world sites x C
+        assert moved == (world - 1) * B * (T // world) * (HW // world) * C * 2

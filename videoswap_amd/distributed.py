@@ -13,6 +13,12 @@ RCCL over xGMI on ROCm; "gloo" is used by the CPU tests and by single-GPU emulat
      * the reference's ResnetBlock3D / conv_norm_out GroupNorm pools statistics over frames (resnet.py:166,177;
        unet.py:474): the fp32 partial sums produced by `vsx_groupnorm_stats` are all-gathered (`gn_hook`) and reduced
        in rank order by `vsx_groupnorm_apply`, so every rank computes bit-identical statistics.
+   `FrameShard(..., exchange='sites')` replaces the 40 K|V all-gathers by TWO all-to-alls per motion module: after the
+   module's per-frame GroupNorm and `proj_in` the activation is re-sharded from frames to SITES (rank r receives the
+   rows of sites [r*hw/P, (r+1)*hw/P) of EVERY frame), the whole temporal transformer (LayerNorm + PE, both temporal
+   attentions, feed-forward: all of it local to a site) runs unchanged on [B, F_total, hw/P, C], and the result is
+   re-sharded back in front of `proj_out` (+ residual).  A rank then moves 2 * (P-1)/P of its OWN activation per motion
+   module instead of receiving (P-1) * 2C columns of everybody's K|V twice: 16 x fewer bytes at P = 8.
    The reference cannot run T > 24 at all (PositionalEncoding max_len 24, motion_module.py:237-255): the long-clip
    model is the same architecture with `temporal_position_encoding_max_len` extended (closed-form sinusoid).
 """
@@ -51,6 +57,19 @@ def _all_gather_into(out, t, group=None):
     return out
 
 
+def _all_to_all(out, t, group=None):
+    """`t` [world, n] -> `out` [world, n]: block p of `t` goes to rank p, block s of `out` comes from rank s.  ONE
+    collective; with gloo, GPU tensors are staged through the host (CPU tests, single-GPU emulation)."""
+    assert out.is_contiguous() and t.is_contiguous() and out.numel() == t.numel()
+    if dist.get_backend(group) == 'nccl' or not t.is_cuda:
+        dist.all_to_all_single(out.view(-1), t.view(-1), group=group)
+        return out
+    host_out = torch.empty(out.numel(), dtype=out.dtype)
+    dist.all_to_all_single(host_out, t.detach().cpu().view(-1), group=group)
+    out.view(-1).copy_(host_out)
+    return out
+
+
 class RcclComm:
     """The library's own RCCL communicator (include/vsx.h: vsx_comm_*): one per process.  The 128-byte unique id is
     created by rank 0 and broadcast through torch.distributed's store-backed object collective (out-of-band: any
@@ -84,7 +103,11 @@ class FrameShard:
     emulation).  Either way each exchange is ONE collective per batch item into a preallocated buffer laid out as the
     attention kernel reads it ([B, F_total, hw, 2C]: K = columns [0, C), V = [C, 2C))."""
 
-    def __init__(self, total_frames, group=None, backend=None):
+    def __init__(self, total_frames, group=None, backend=None, exchange='kv'):
+        if exchange not in ('kv', 'sites'):
+            raise ValueError("exchange must be 'kv' (all-gather of the temporal K|V) or 'sites' (frame <-> site "
+                             "all-to-all around every motion module)")
+        self.exchange = exchange
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -97,7 +120,8 @@ class FrameShard:
             backend = 'rccl' if dist.get_backend(group) == 'nccl' else 'torch'
         self.backend = backend
         self.comm = RcclComm(group) if backend == 'rccl' else None
-        self.bytes_gathered = 0                  # K|V bytes received per forward
+        self.bytes_gathered = 0                  # bytes received from the other ranks (K|V rows or re-sharded
+                                                 # activations) since construction
 
     # ---- GroupNorm partial sums ----------------------------------------------------------------------------------
     def gn_hook(self, partial):
@@ -152,6 +176,39 @@ class FrameShard:
             torch.cuda.current_stream().wait_event(done)
         return out.view(-1, c2), self.total_frames
 
+    # ---- frames <-> sites (exchange = 'sites') ---------------------------------------------------------------------
+    def sites_per_rank(self, hw):
+        if hw % self.world:
+            raise ValueError(f"exchange='sites' needs every level's site count to split over the ranks: {hw} sites, "
+                             f"{self.world} ranks (use exchange='kv' for this latent size)")
+        return hw // self.world
+
+    def to_sites(self, y, b, hw):
+        """y [b*f_local*hw, C] (this rank's frames, all sites) -> [b*F_total*hw_local, C] (all frames, this rank's
+        sites), rows in (b, frame, site) order with the frames in rank order = global order.  One all-to-all."""
+        c = y.shape[-1]
+        f, p = self.local_frames, self.world
+        hl = self.sites_per_rank(hw)
+        # destination-major send blocks [p][b, f, hl, c]: one strided copy (the only extra pass on this side)
+        send = y.view(b, f, p, hl, c).permute(2, 0, 1, 3, 4).contiguous()
+        recv = torch.empty_like(send)                                    # [source rank s][b, f(s), hl, c]
+        _all_to_all(recv.view(p, -1), send.view(p, -1), self.group)
+        self.bytes_gathered += (p - 1) * b * f * hl * c * y.element_size()
+        # frames of source s are global frames [s*f, (s+1)*f): (s, b, f) -> (b, s, f)
+        return recv.permute(1, 0, 2, 3, 4).reshape(b * p * f * hl, c)
+
+    def to_frames(self, ys, b, hw):
+        """inverse of `to_sites`: ys [b*F_total*hw_local, C] -> [b*f_local*hw, C]."""
+        c = ys.shape[-1]
+        f, p = self.local_frames, self.world
+        hl = self.sites_per_rank(hw)
+        send = ys.view(b, p, f, hl, c).permute(1, 0, 2, 3, 4).contiguous()   # block d = frames owned by rank d
+        recv = torch.empty_like(send)                                        # [source s][b, f, hl(s), c]
+        _all_to_all(recv.view(p, -1), send.view(p, -1), self.group)
+        self.bytes_gathered += (p - 1) * b * f * hl * c * ys.element_size()
+        # sites of source s are [s*hl, (s+1)*hl): (s, b, f, hl) -> (b, f, s, hl)
+        return recv.permute(1, 2, 0, 3, 4).reshape(b * f * hw, c)
+
     # ---- wiring ------------------------------------------------------------------------------------------------
     def install(self, unet):
         """Attach the hooks to a videoswap_amd AnimateDiffUNet3DModel (idempotent)."""
@@ -160,8 +217,9 @@ class FrameShard:
         for m in unet.modules():
             proc = getattr(m, 'processor', None)
             if isinstance(proc, VanillaAttentionProcessor):
-                proc.kv_gather = self
-                proc.frame_offset = self.frame_offset
+                if self.exchange == 'kv':        # 'sites': the temporal transformer sees every frame, no hook needed
+                    proc.kv_gather = self
+                    proc.frame_offset = self.frame_offset
                 if proc.pos_encoder is not None and proc.pos_encoder.pe.shape[1] < self.total_frames:
                     raise ValueError('temporal_position_encoding_max_len is smaller than the clip: build the UNet with '
                                      f'max_len >= {self.total_frames}')

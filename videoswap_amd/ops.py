@@ -307,9 +307,21 @@ def temporal_attention(q, k, v, B, fq, fk, hw, heads, scale):
     out = torch.empty(q.shape[0], C, dtype=_F16, device=q.device)
     if FlopCounter.enabled:
         FlopCounter.attention += 4.0 * B * hw * fq * fk * C
-    check(_lib.load().vsx_temporal_attention_f16(_p(q), _p(k), _p(v), _p(out), B, fq, fk, hw, heads, C // heads,
-                                                 q.stride(0), k.stride(0), C, float(scale), _stream()),
-          'vsx_temporal_attention_f16')
+    fn = _lib.load().vsx_temporal_attention_f16
+    if fq <= 32 or fk > 128:
+        check(fn(_p(q), _p(k), _p(v), _p(out), B, fq, fk, hw, heads, C // heads, q.stride(0), k.stride(0), C,
+                 float(scale), _stream()), 'vsx_temporal_attention_f16')
+        return out
+    # more than 32 query frames (a long clip whose frames are all local: FrameShard exchange='sites'): the matrix-core
+    # kernel takes up to 32 query frames against up to 128 key frames, so the queries go in blocks of 32 frames; a
+    # block's rows are contiguous within one batch item, hence one launch per (batch item, block)
+    for b in range(B):
+        kb, vb = k[b * fk * hw:(b + 1) * fk * hw], v[b * fk * hw:(b + 1) * fk * hw]
+        for f0 in range(0, fq, 32):
+            n = min(32, fq - f0)
+            r0 = (b * fq + f0) * hw
+            check(fn(_p(q[r0:r0 + n * hw]), _p(kb), _p(vb), _p(out[r0:r0 + n * hw]), 1, n, fk, hw, heads, C // heads,
+                     q.stride(0), k.stride(0), C, float(scale), _stream()), 'vsx_temporal_attention_f16')
     return out
 
 

@@ -28,10 +28,11 @@ from .layers import (FeedForward, GroupNorm, InflatedConv3d, LayerNorm, Linear, 
 
 class Geometry:
     """Shape of the channels-last activation [B*F, H, W, C] travelling through the blocks."""
-    __slots__ = ('B', 'F', 'gn_hook', 'gn_frames')
+    __slots__ = ('B', 'F', 'gn_hook', 'gn_frames', 'site_shard')
 
-    def __init__(self, B, F, gn_hook=None, gn_frames=None):
+    def __init__(self, B, F, gn_hook=None, gn_frames=None, site_shard=None):
         self.B, self.F = B, F
+        self.site_shard = site_shard  # frame-sharded mode with exchange='sites': frames <-> sites around motion modules
         self.gn_hook = gn_hook        # frame-sharded mode: all-reduce of 5-D GroupNorm partial sums
         self.gn_frames = gn_frames    # global frame count behind those statistics
 
@@ -241,8 +242,19 @@ class TemporalTransformer3DModel(nn.Module):
         bf, h, w, c = x.shape
         y = self.norm(x, bf)
         y = self.proj_in(y.view(bf, h * w, c))
-        for block in self.transformer_blocks:
-            y = block(y, video_length=geo.F)
+        shard = geo.site_shard
+        if shard is None:
+            for block in self.transformer_blocks:
+                y = block(y, video_length=geo.F)
+        else:
+            # long clip, frames sharded over the ranks: everything between proj_in and proj_out is local to a SITE, so
+            # re-shard frames -> sites once, run the blocks on all F_total frames of this rank's sites, re-shard back
+            inner = y.shape[-1]
+            ys = shard.to_sites(y.view(-1, inner), geo.B, h * w)
+            ys = ys.view(geo.B * shard.total_frames, -1, inner)
+            for block in self.transformer_blocks:
+                ys = block(ys, video_length=shard.total_frames)
+            y = shard.to_frames(ys.view(-1, inner), geo.B, h * w).view(bf, h * w, inner)
         y = self.proj_out(y, residual=x.view(bf, h * w, c))
         return y.view(bf, h, w, c)
 
@@ -617,7 +629,8 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         into a HIP graph (`enable_hip_graphs`).  `residuals`: channels-last adapter maps or None."""
         B, _, F, H, W = sample.shape
         shard = self._frame_shard
-        geo = Geometry(B, F, None if shard is None else shard.gn_hook, None if shard is None else shard.total_frames)
+        geo = Geometry(B, F, None if shard is None else shard.gn_hook, None if shard is None else shard.total_frames,
+                       shard if shard is not None and shard.exchange == 'sites' else None)
 
         x = ops.pack_latents(sample.contiguous(), 8)            # [B*F, H, W, 8] (latent channels zero-padded)
         x = self.conv_in(x)
