@@ -4,7 +4,7 @@ oracle on the GPU, and its state-dict layout with the transformers-4.25 key name
 import pytest
 import torch
 
-from util import rel_l2
+from util import DEV, rel_l2
 
 
 def _ids(n=3, vocab=300, seed=1):
@@ -51,8 +51,8 @@ def test_product_clip_state_dict_layout():
     assert p.get_input_embeddings().weight.shape == (326, 64) and float(p.get_input_embeddings().weight.detach()[310:].abs().sum()) == 0
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('full', [False, True])
+@pytest.mark.parametrize('full', [pytest.param(False, marks=pytest.mark.device),
+                                  pytest.param(True, marks=pytest.mark.gpu)])
 def test_product_clip_matches_oracle(full):
     from oracle import clip as oclip
     from videoswap_amd.clip import CLIPTextConfig, CLIPTextModel
@@ -61,7 +61,7 @@ def test_product_clip_matches_oracle(full):
     ora = oclip.synth_weights_(oclip.CLIPTextModel(**cfg)).eval()
     prod = CLIPTextModel(CLIPTextConfig(**cfg)).eval()
     prod.load_state_dict(ora.state_dict(), strict=True)
-    prod = prod.to('cuda', torch.float16)
+    prod = prod.to(DEV, torch.float16)
     ids = _ids(n=17, vocab=cfg['vocab_size'])             # 16 per-layer ED-LoRA prompts + the negative prompt
     with torch.no_grad():
         want = ora(ids)[0]

@@ -13,7 +13,7 @@ import sys
 import pytest
 import torch
 
-from util import GOLDEN, ROOT
+from util import DEV, GOLDEN, ROOT
 
 YML = '/root/reference/options/test_videoswap/animal/2001_catheadturn_T05_Iter100/2001_catheadturn_T05_Iter100.yml'
 OVERRIDES = {'datasets.num_frames': 4, 'val.editing_config.num_inference_steps': 2, 'mixed_precision': 'no',
@@ -94,14 +94,19 @@ def _frames_tensor(frames):
     return torch.from_numpy(np.stack([np.asarray(f, dtype=np.float32) for f in frames]))
 
 
-@pytest.mark.gpu
+@pytest.mark.device
 def test_config1_product_matches_oracle_flow(tmp_path):
-    """Same tiny workspace: the HIP product through videoswap_amd.runner.test against the oracle flow on the device
-    (fp32).  Outputs are decoded 8-bit frames: mean absolute difference in grey levels."""
+    """Same tiny workspace: the product through videoswap_amd.runner.test against the oracle flow on the same device
+    (fp32).  Outputs are decoded 8-bit frames: mean absolute difference in grey levels.  (Without a GPU: the host
+    mirror on tests/host_emulation.py, 256x256 frames to bound the CPU time.)"""
     from oracle.validation import oracle_classes
-    opt, _ = _prepare(tmp_path, 'tiny', {'mixed_precision': 'fp16'})
-    got, save_dir = _run(opt, tmp_path, 'cuda')
-    ref, _ = _run(dict(opt, mixed_precision='no'), tmp_path, 'cuda', oracle_classes())
+    extra = {'mixed_precision': 'fp16'}
+    if DEV == 'cpu':
+        extra['datasets.video_transform'] = [{'type': 'Resize', 'size': 256}, {'type': 'ToTensor'},
+                                             {'type': 'Normalize', 'mean': [0.5], 'std': [0.5]}]
+    opt, _ = _prepare(tmp_path, 'tiny', extra)
+    got, save_dir = _run(opt, tmp_path, DEV)
+    ref, _ = _run(dict(opt, mixed_precision='no'), tmp_path, DEV, oracle_classes())
     for key in ref:
         a, b = _frames_tensor(got[key]), _frames_tensor(ref[key])
         mad = float((a - b).abs().mean())

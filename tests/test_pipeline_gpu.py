@@ -2,9 +2,9 @@
 import pytest
 import torch
 
-from util import oracle_unet, product_unet_from, rel_l2
+from util import DEV, oracle_unet, product_unet_from, rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.device
 
 
 @pytest.fixture(scope='module')
@@ -45,9 +45,9 @@ def test_inversion_and_guided_sampling(models):
     txt, neg = torch.randn(1, 77, 64, generator=g), torch.randn(1, 77, 64, generator=g)
     steps = 4
     inv_ref, out_ref = oracle_loops(ora, x, txt, neg, steps, 7.5)
-    pipe = VideoSwapPipeline(unet=prod, scheduler=DDIMScheduler(**SD15_SCHEDULER_CONFIG)).to('cuda')
-    inv = pipe.invert(latents=x.half().cuda(), prompt_embeds=txt.half().cuda(), num_inference_steps=steps).latents
-    out = pipe(prompt_embeds=txt.half().cuda(), negative_prompt_embeds=neg.half().cuda(), latents=inv,
+    pipe = VideoSwapPipeline(unet=prod, scheduler=DDIMScheduler(**SD15_SCHEDULER_CONFIG)).to(DEV)
+    inv = pipe.invert(latents=x.half().to(DEV), prompt_embeds=txt.half().to(DEV), num_inference_steps=steps).latents
+    out = pipe(prompt_embeds=txt.half().to(DEV), negative_prompt_embeds=neg.half().to(DEV), latents=inv,
                num_inference_steps=steps, guidance_scale=7.5, output_type='latent').videos
     e_inv, e_out = rel_l2(inv.float().cpu(), inv_ref), rel_l2(out.float().cpu(), out_ref)
     print(f'inversion rel-L2 {e_inv:.3e}; inversion+sampling rel-L2 {e_out:.3e}')
@@ -65,13 +65,13 @@ def test_adapter_matches_oracle_and_feeds_the_unet(models):
     o = oadapter.SparsePointAdapter(embedding_channels=1280, channels=chans).eval()
     p = SparsePointAdapter(embedding_channels=1280, channels=chans).eval()
     p.load_state_dict(o.state_dict(), strict=True)
-    p = p.to('cuda', torch.float16)
-    data = synthetic_clip(seed=9, frames=3, height=16, width=24, text_dim=64, points=6)
+    p = p.to(DEV, torch.float16)
+    data = synthetic_clip(seed=9, frames=3, height=16, width=24, text_dim=64, points=6, device=DEV)
     cond = data['conditions']
     tracks16 = cond['pred_tracks'].half().float()     # the reference holds the tracks in fp16
     with torch.no_grad():
         ref = o(tracks16, cond['img_size'], cond['point_embedding'], index_list=[0, 1, 2, 4])
-    got = p(cond['pred_tracks'], cond['img_size'], cond['point_embedding'].half().cuda(), index_list=[0, 1, 2, 4])
+    got = p(cond['pred_tracks'], cond['img_size'], cond['point_embedding'].half().to(DEV), index_list=[0, 1, 2, 4])
     for level, (r, gt) in enumerate(zip(ref, SparsePointAdapter.to_reference_layout(got))):
         assert gt.shape == r.shape
         assert rel_l2(gt.float().cpu(), r) < 5e-3, level
@@ -84,8 +84,8 @@ def test_foreign_processor_protocol(models):
     from oracle.diffusers_restated import AttnProcessor as ForeignProcessor
     cfg, ora, prod = models
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(1, 4, 2, 16, 16, generator=g).half().cuda()
-    txt = torch.randn(1, 77, 64, generator=g).half().cuda()
+    x = torch.randn(1, 4, 2, 16, 16, generator=g).half().to(DEV)
+    txt = torch.randn(1, 77, 64, generator=g).half().to(DEV)
     with torch.no_grad():
         base = prod(x, 301, txt).sample
         saved = {}

@@ -7,25 +7,25 @@ import sys
 import pytest
 import torch
 
-from util import GOLDEN, load_golden, rel_l2
+from util import DEV, GOLDEN, load_golden, rel_l2, sync
 
 sys.path.insert(0, GOLDEN)
 import toy  # noqa: E402
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.device
 
 
 def product_attention(sd, cross):
     from videoswap_amd.attention import Attention
     a = Attention(query_dim=320, cross_attention_dim=768 if cross else None, heads=8, dim_head=40).eval()
     a.load_state_dict(sd, strict=True)
-    return a.to('cuda', torch.float16)
+    return a.to(DEV, torch.float16)
 
 
 def test_product_processors_match_the_reference_processors():
     from videoswap_amd.attention import AttnControlProcessor, EDLoRA_AttnControlProcessor, EDLoRA_AttnProcessor
     gold = load_golden('processors.pt')['cases']
-    inp = {k: v.half().cuda() for k, v in toy.attention_inputs().items()}
+    inp = {k: v.half().to(DEV) for k, v in toy.attention_inputs().items()}
     self_sd, cross_sd = toy.attention_weights()
     a_self, a_cross = product_attention(self_sd, False), product_attention(cross_sd, True)
     c = toy.ToyController()
@@ -40,7 +40,7 @@ def test_product_processors_match_the_reference_processors():
                                                                                      inp['text_layers']),
             'edlora_control_self_up': EDLoRA_AttnControlProcessor(5, 'up', c)(a_self, inp['hidden'], None),
         }
-    torch.cuda.synchronize()
+    sync()
     for k, v in got.items():
         e = rel_l2(v.float().cpu(), gold[k])
         print(f'{k}: rel-L2 {e:.2e}')
@@ -57,8 +57,8 @@ def test_text_shared_by_frames_equals_reference_repeat():
     inp = toy.attention_inputs()
     _, cross_sd = toy.attention_weights()
     a = product_attention(cross_sd, True)
-    hidden = inp['hidden'].half().cuda()
-    text = inp['text_layers'][:1].half().cuda()            # one clip of 2 frames
+    hidden = inp['hidden'].half().to(DEV)
+    text = inp['text_layers'][:1].half().to(DEV)            # one clip of 2 frames
     with torch.no_grad():
         shared = EDLoRA_AttnProcessor(3)(a, hidden, text, video_length=2)
         repeated = EDLoRA_AttnProcessor(3)(a, hidden, text.repeat(2, 1, 1, 1))

@@ -8,12 +8,13 @@ import copy
 import pytest
 import torch
 
-from util import oracle_unet, product_unet_from, rel_l2
+from util import DEV, oracle_unet, product_unet_from, rel_l2
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.device
 
 SOURCE = 'a silver jeep driving down a curvy road in the countryside'
-STEPS, FRAMES, HW = 4, 2, 64     # 64x64 latents: only the 16x16 / 8x8 layers are stored, as in the real model
+STEPS, FRAMES = 4, 2
+HW = 64 if DEV == 'cuda' else 32     # 64x64 latents on the GPU: only the 16x16 / 8x8 layers are stored, as in the real model
 
 
 def synthetic_lora(state_dict, seed=4, rank=4):
@@ -61,7 +62,7 @@ def test_full_swap_flow_matches_oracle():
     oad = oadapter.SparsePointAdapter(1280, chans).eval()
     pad = SparsePointAdapter(embedding_channels=1280, channels=chans).eval()
     pad.load_state_dict(oad.state_dict(), strict=True)
-    pad = pad.to('cuda', torch.float16)
+    pad = pad.to(DEV, torch.float16)
 
     data = synthetic_clip(seed=21, frames=FRAMES, height=HW, width=HW, text_dim=64, points=5, device='cpu',
                           dtype=torch.float32)
@@ -79,9 +80,9 @@ def test_full_swap_flow_matches_oracle():
     # ---------------- product on the GPU ----------------
     tok = WhitespaceTokenizer()
     pipe = VideoSwapPipeline(unet=prod, adapter=pad, tokenizer=tok, scheduler=DDIMScheduler(**SD15_SCHEDULER_CONFIG),
-                             text_encoder=SyntheticTextEncoder(dim=64, dtype=torch.float16, device='cuda')).to('cuda')
+                             text_encoder=SyntheticTextEncoder(dim=64, dtype=torch.float16, device=DEV)).to(DEV)
     before = copy.deepcopy(prod.state_dict())
-    video = latents[0].permute(1, 0, 2, 3).contiguous().half().cuda()          # [F,4,h,w] "video" of latents
+    video = latents[0].permute(1, 0, 2, 3).contiguous().half().to(DEV)          # [F,4,h,w] "video" of latents
     edited = pipe.validation(video, conditions, SOURCE, editing_config, lora_loader=lambda path: lora)
     got = edited['0'].float().cpu()
     # weights restored bit-exactly, processors reset to the ED-LoRA-free state is not required by the reference

@@ -1,4 +1,4 @@
-"""GPU parity of the HIP-backed AnimateDiffUNet3DModel against the golden vectors produced by the reference's own
+"""Parity of the HIP-backed AnimateDiffUNet3DModel (GPU box: the kernels; here: the host mirror on tests/host_emulation.py) against the golden vectors produced by the reference's own
 model code (tests/golden/unet_tiny.pt) and against the fp32 CPU oracle.
 
 Tolerance: the fp16 GPU result must be within 2x the rel-L2 error that the oracle itself shows
@@ -8,9 +8,9 @@ import copy
 import pytest
 import torch
 
-from util import cosine, load_golden, oracle_unet, product_unet_from, rel_l2
+from util import cosine, DEV, load_golden, oracle_unet, product_unet_from, rel_l2, sync
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.device
 
 
 @pytest.fixture(scope='module')
@@ -24,11 +24,11 @@ def setup():
 def run_product(prod, case):
     res = None
     if case['residuals'] is not None:
-        res = [r.half().cuda() for r in case['residuals']]
+        res = [r.half().to(DEV) for r in case['residuals']]
     with torch.no_grad():
-        out = prod(case['sample'].half().cuda(), torch.tensor(case['timestep']), case['text'].half().cuda(),
+        out = prod(case['sample'].half().to(DEV), torch.tensor(case['timestep']), case['text'].half().to(DEV),
                    down_block_additional_residuals=res, return_dict=False)[0]
-    torch.cuda.synchronize()
+    sync()
     return out.float().cpu()
 
 
@@ -52,7 +52,7 @@ def test_unet_matches_reference_golden(setup, name):
 def test_unet_output_object_and_determinism(setup):
     blob, ora, prod = setup
     case = blob['cases']['plain_T4_16x16']
-    x, txt = case['sample'].half().cuda(), case['text'].half().cuda()
+    x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
     with torch.no_grad():
         a = prod(x, 481, txt)
         b = prod(x, torch.tensor([481]), txt, return_dict=False)
@@ -64,9 +64,9 @@ def test_unet_output_object_and_determinism(setup):
 def test_unet_pops_adapter_residual_list(setup):
     blob, ora, prod = setup
     case = blob['cases']['cfg_adapter_T3_16x24']
-    res = [r.half().cuda() for r in case['residuals']]
+    res = [r.half().to(DEV) for r in case['residuals']]
     with torch.no_grad():
-        prod(case['sample'].half().cuda(), 21, case['text'].half().cuda(), down_block_additional_residuals=res)
+        prod(case['sample'].half().to(DEV), 21, case['text'].half().to(DEV), down_block_additional_residuals=res)
     assert res == []          # the UNet pops from the caller's list (unet.py:422,435)
 
 
@@ -74,8 +74,8 @@ def test_zero_initialised_motion_module_is_identity(setup):
     """With AnimateDiff's zero-init proj_out the temporal path must contribute exactly nothing."""
     blob, ora, prod = setup
     from videoswap_amd.unet import VanillaTemporalModule, Geometry
-    mm = VanillaTemporalModule(64, temporal_position_encoding=True, num_transformer_block=1).half().cuda()
-    x = torch.randn(8, 4, 4, 64, device='cuda', dtype=torch.float16)
+    mm = VanillaTemporalModule(64, temporal_position_encoding=True, num_transformer_block=1).half().to(DEV)
+    x = torch.randn(8, 4, 4, 64, device=DEV, dtype=torch.float16)
     with torch.no_grad():
         y = mm(x, Geometry(2, 4))
     assert torch.equal(x, y)
@@ -86,7 +86,7 @@ def test_step_invariant_caches_follow_inputs_and_weights(setup):
     in-place edit of the text embedding or a weight reload is picked up."""
     blob, ora, prod = setup
     case = blob['cases']['plain_T4_16x16']
-    x, txt = case['sample'].half().cuda(), case['text'].half().cuda()
+    x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
     with torch.no_grad():
         prod.clear_step_caches()
         cold = prod(x, 481, txt).sample
@@ -123,14 +123,15 @@ GRAPHS = pytest.mark.skipif(os.environ.get('VSX_TEST_GRAPHS') != '1',
                             reason='HIP-graph replay is opt-in until it has been timed on hardware (VSX_TEST_GRAPHS=1)')
 
 
+@pytest.mark.gpu
 @GRAPHS
 def test_hip_graph_replay_is_bit_identical_to_eager(setup):
     """The captured forward replays the same kernels on the same data layout: bit-identical outputs, across
     timesteps, texts, adapter residuals and a weight reload (which must drop the graph)."""
     blob, ora, prod = setup
     case = blob['cases']['cfg_adapter_T3_16x24']
-    x, txt = case['sample'].half().cuda(), case['text'].half().cuda()
-    res = [r.half().cuda() for r in case['residuals']]
+    x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
+    res = [r.half().to(DEV) for r in case['residuals']]
     with torch.no_grad():
         eager = [prod(x, t, txt).sample for t in (21, 481)]
         eager_res = prod(x, 21, txt, down_block_additional_residuals=list(res)).sample
@@ -162,13 +163,14 @@ def test_hip_graph_replay_is_bit_identical_to_eager(setup):
             prod.enable_hip_graphs(False)
 
 
+@pytest.mark.gpu
 @GRAPHS
 def test_hip_graphs_step_aside_for_controllers(setup):
     """Prompt-to-Prompt control processors keep host state per call: the graph path must not be taken."""
     from videoswap_amd import control
     blob, ora, prod = setup
     case = blob['cases']['plain_T4_16x16']
-    x, txt = case['sample'].half().cuda(), case['text'].half().cuda()
+    x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
     pipe = type('P', (), {'unet': prod})()
     with torch.no_grad():
         prod.enable_hip_graphs(True)

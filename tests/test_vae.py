@@ -5,7 +5,7 @@ the fp32 oracle."""
 import pytest
 import torch
 
-from util import rel_l2
+from util import DEV, rel_l2
 
 
 def test_vae_state_dict_layout_matches_diffusers_layout():
@@ -54,8 +54,8 @@ def test_image_processor_roundtrip():
     assert torch.equal(proc.preprocess(back), x)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('full', [False, True])
+@pytest.mark.parametrize('full', [pytest.param(False, marks=pytest.mark.device),
+                                  pytest.param(True, marks=pytest.mark.gpu)])
 def test_vae_encode_decode_match_oracle(full):
     from oracle import vae as ovae
     from videoswap_amd.vae import SD15_VAE_CONFIG, AutoencoderKL
@@ -64,23 +64,23 @@ def test_vae_encode_decode_match_oracle(full):
     o = ovae.synth_weights_(ovae.AutoencoderKL(**cfg)).eval()
     p = AutoencoderKL(**cfg).eval()
     p.load_state_dict(o.state_dict(), strict=True)
-    p = p.to('cuda', torch.float16)
+    p = p.to(DEV, torch.float16)
     g = torch.Generator().manual_seed(3)
     x = torch.rand(3, 3, *size, generator=g) * 2 - 1
-    odev = o.to('cuda')
+    odev = o.to(DEV)
     with torch.no_grad():
-        ref_m = odev.moments(x.cuda()).cpu()
-        dist = p.encode(x.half().cuda()).latent_dist
+        ref_m = odev.moments(x.to(DEV)).cpu()
+        dist = p.encode(x.half().to(DEV)).latent_dist
         assert dist.parameters.shape == ref_m.shape
         e_mom = rel_l2(dist.parameters.float().cpu(), ref_m)
         noise = torch.randn(ref_m[:, :4].shape, generator=g)
         e_mode = rel_l2(dist.mode().float().cpu(), torch.chunk(ref_m, 2, 1)[0])
         z = torch.randn(3, 4, size[0] // 8, size[1] // 8, generator=g)
-        ref_d = odev.decode(z.cuda()).cpu()
-        dec = p.decode(z.half().cuda()).sample
+        ref_d = odev.decode(z.to(DEV)).cpu()
+        dec = p.decode(z.half().to(DEV)).sample
         e_dec = rel_l2(dec.float().cpu(), ref_d)
         p.enable_slicing()
-        dec2 = p.decode(z.half().cuda(), return_dict=False)[0]
+        dec2 = p.decode(z.half().to(DEV), return_dict=False)[0]
     print(f'vae {"SD-1.5" if full else "tiny"}: moments {e_mom:.2e}, mode {e_mode:.2e}, decode {e_dec:.2e}')
     assert dec.shape == (3, 3, *size) and torch.equal(dec, dec2)
     assert e_mom < 6e-3 and e_mode < 6e-3 and e_dec < 6e-3

@@ -8,6 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# where the product side of a `device` test lives: the GPU when there is one, else CPU tensors under tests/host_emulation.py
+DEV = 'cuda' if torch.cuda.is_available() else 'cpu'
+
+
+def sync():
+    if DEV == 'cuda':
+        torch.cuda.synchronize()
 
 
 def load_golden(name):
@@ -36,7 +43,7 @@ def oracle_unet(cfg=None, seed=1234):
     return m
 
 
-def product_unet_from(oracle_model, cfg, device='cuda', dtype=torch.float16):
+def product_unet_from(oracle_model, cfg, device=DEV, dtype=torch.float16):
     """Build the HIP-backed UNet and load the oracle's (reference-keyed) state dict into it."""
     from videoswap_amd.unet import AnimateDiffUNet3DModel
     m = AnimateDiffUNet3DModel(**cfg).eval()

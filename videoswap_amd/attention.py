@@ -94,22 +94,7 @@ class Attention(nn.Module):
         """softmax(scale * q k^T) for head-batched [B*heads, N, d] operands (diffusers signature)."""
         if attention_mask is not None:
             raise NotImplementedError('attention masks are never used on the VideoSwap path')
-        from ._lib import GemmDesc
-        query, key = query.contiguous(), key.contiguous()
-        nbh, nq, d = query.shape
-        nk = key.shape[1]
-        probs = torch.empty(nbh, nq, nk, dtype=query.dtype, device=query.device)
-        g = GemmDesc()
-        g.M, g.N, g.K = nq, nk, d
-        g.batch0, g.batch1 = nbh, 1
-        g.A = query.data_ptr(); g.lda = d; g.a_bs0 = nq * d
-        g.B = key.data_ptr(); g.ldb = d; g.b_bs0 = nk * d
-        g.C = probs.data_ptr(); g.ldc = nk; g.c_bs0 = nq * nk
-        g.alpha = float(self.scale)
-        ops.gemm(g)
-        from ._lib import check, load
-        check(load().vsx_softmax_rows(ops._p(probs), nbh * nq, nk, nk, ops._stream()), 'vsx_softmax_rows')
-        return probs
+        return ops.head_scores(query, key, self.scale)
 
     def prepare_attention_mask(self, attention_mask, target_length, batch_size=None, out_dim=3):
         if attention_mask is None:

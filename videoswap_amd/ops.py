@@ -228,6 +228,26 @@ def attention_scores(q, k, heads, scale, kv_div=1, causal=False):
     return buf[..., :nk]
 
 
+def head_scores(query, key, scale):
+    """softmax(scale * q k^T) for head-batched operands [B*heads, N, d] x [B*heads, Nk, d] -> [B*heads, N, Nk]
+    (diffusers `Attention.get_attention_scores`, the surface foreign processors call)."""
+    query, key = query.contiguous(), key.contiguous()
+    _chk(query, 'query'); _chk(key, 'key')
+    nbh, nq, d = query.shape
+    nk = key.shape[1]
+    probs = torch.empty(nbh, nq, nk, dtype=_F16, device=query.device)
+    g = GemmDesc()
+    g.M, g.N, g.K = nq, nk, d
+    g.batch0, g.batch1 = nbh, 1
+    g.A = query.data_ptr(); g.lda = d; g.a_bs0 = nq * d
+    g.B = key.data_ptr(); g.ldb = d; g.b_bs0 = nk * d
+    g.C = probs.data_ptr(); g.ldc = nk; g.c_bs0 = nq * nk
+    g.alpha = float(scale)
+    gemm(g)
+    check(_lib.load().vsx_softmax_rows(_p(probs), nbh * nq, nk, nk, _stream()), 'vsx_softmax_rows')
+    return probs
+
+
 def attention_pv(probs, vt, kv_div=1):
     """out[b, q, h*d + c] = sum_t probs[b, h, q, t] * vt[b // kv_div, h*d + c, t]; probs from attention_scores
     (possibly edited in place by a controller; must still be a view of a buffer with padded rows)."""
