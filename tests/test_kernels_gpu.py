@@ -201,6 +201,13 @@ def both_gemm_paths(fn):
     return a, b
 
 
+def _sched(sched):
+    """piece schedule of the persistent kernel under test: the case's own, or VSX_TEST_PP_SCHED (a candidate schedule of
+    the development library, VSX_LIB_VARIANT=next) for every case"""
+    import os
+    return int(os.environ.get('VSX_TEST_PP_SCHED', sched))
+
+
 @pytest.mark.parametrize('M,N,K,res,sched', [
     (65536, 320, 320, True, 0), (65536, 320, 1280, True, 1), (65536, 960, 320, False, 2), (61440, 640, 640, False, 0),
     (131072, 320, 320, True, 0), (8192, 1280, 1280, True, 0), (8192, 3840, 1280, False, 0), (32768, 640, 2560, True, 0),
@@ -212,7 +219,7 @@ def both_gemm_paths(fn):
 def test_persistent_linear(M, N, K, res, sched):
     x, w, b = rnd(M, K, seed=90), rnd(N, K, seed=91, scale=K ** -0.5), rnd(N, seed=92)
     r = rnd(M, N, seed=93) if res else None
-    ops().set_option('pp_sched', sched)
+    ops().set_option('pp_sched', _sched(sched))
     old, new = both_gemm_paths(lambda: ops().linear(x, w, b, residual=r))
     ref = x.float() @ w.float().t() + b.float()
     if res:
@@ -225,6 +232,7 @@ def test_persistent_linear(M, N, K, res, sched):
 @pytest.mark.parametrize('M,N,K', [(65536, 1280, 320), (32768, 2560, 640), (8192, 5120, 1280), (20000, 160, 320)])
 def test_persistent_geglu(M, N, K):
     x, w, b = rnd(M, K, seed=94), rnd(2 * N, K, seed=95, scale=K ** -0.5), rnd(2 * N, seed=96)
+    ops().set_option('pp_sched', _sched(0))
     old, new = both_gemm_paths(lambda: ops().linear(x, w, b, geglu=True))
     y = x.float() @ w.float().t() + b.float()
     assert rel_err(new, y[:, :N] * F.gelu(y[:, N:])) < 2e-3
@@ -249,7 +257,7 @@ def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched):
     Ho = (2 * H if ups else H) // stride
     Wo = (2 * W if ups else W) // stride
     rowvec, res = rnd(nimg, Cout, seed=101), rnd(nimg, Ho, Wo, Cout, seed=102)
-    ops().set_option('pp_sched', sched)
+    ops().set_option('pp_sched', _sched(sched))
     old, new = both_gemm_paths(lambda: ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec,
                                                     rows_per_vec=Ho * Wo, residual=res))
     ref = conv_ref(x, w, b, stride, x2, ups) + rowvec.float()[:, None, None, :] + res.float()

@@ -3,6 +3,8 @@ persistent ping-pong kernel with 256-row tiles (gemm_pp = 2), with 128-row tiles
 (gemm_pp = 1, what the product runs).
 
     python tools/gemm_ab.py [--batch 2] [--rounds 5] > gpurun_out/gemm_ab.txt
+    VSX_LIB_VARIANT=next python tools/gemm_ab.py --scheds 0,3,4,5,6      # piece schedules of the development library:
+                                                                          # tile kernels vs 256-row persistent tiles per schedule
 
 Variants are interleaved round by round inside ONE process (a cross-process comparison has >3 % noise); the table shows
 the median of the per-round times, TFLOP/s of the best variant and the speed-up over the tile kernels.  Shapes: one
@@ -47,14 +49,27 @@ def shapes(B):
     return out
 
 
-def make(kind, a):
+def pack_b(w):
+    """piece-major copy of a K-major weight ([N, K] or [N, kh, kw, C]): [N/8][K/64][8 rows][64 halfs], same shape"""
+    n = w.shape[0]
+    k = w.numel() // n
+    assert n % 8 == 0 and k % 64 == 0
+    return w.reshape(n // 8, 8, k // 64, 64).permute(0, 2, 1, 3).contiguous().view(w.shape)
+
+
+def make(kind, a, packed=False):
+    """-> (launch closure, algorithmic FLOP); packed: the closure passes the piece-major weight (development library,
+    pp_sched + 16)"""
+    pk = pack_b if packed else (lambda t: t)
     if kind in ('plain', 'geglu'):
         M, N, K = a['M'], a['N'], a['K']
         x = r(M, K)
         if kind == 'geglu':
             w, b = r(2 * N, K, scale=K ** -0.5), r(2 * N)
+            w = pk(w)
             return (lambda: ops.linear(x, w, b, geglu=True)), 2.0 * M * 2 * N * K
         w, b = r(N, K, scale=K ** -0.5), r(N)
+        w = pk(w)
         res = r(M, N) if a['res'] else None
         return (lambda: ops.linear(x, w, b, residual=res)), 2.0 * M * N * K
     hw = a['hw'] // 2 if a['up'] else a['hw']
@@ -62,6 +77,7 @@ def make(kind, a):
     x2 = r(a['nimg'], hw, hw, a['c2']) if a['c2'] else None
     cin = a['c1'] + a['c2']
     w, b = r(a['co'], 3, 3, cin, scale=(9 * cin) ** -0.5), r(a['co'])
+    w = pk(w)
     ho = a['hw'] // a['stride']
     rv = r(a['nimg'] // 16, a['co'])
     return (lambda: ops.conv2d(x, w, b, x2=x2, stride=a['stride'], upsample=a['up'], rowvec=rv,
@@ -83,28 +99,49 @@ def main():
     ap.add_argument('--batch', type=int, default=2)
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--reps', type=int, default=4)
+    ap.add_argument('--scheds', default='', help='comma-separated pp_sched values: compare piece schedules instead of tile sizes')
+    ap.add_argument('--bm', type=int, default=256, choices=(128, 256), help='row tile of the --scheds comparison')
+    ap.add_argument('--bpack', action='store_true',
+                    help='with --scheds: add every schedule >= 16 as a packed-B variant (development library only); the '
+                         'packed result must equal the unpacked one bit for bit')
     args = ap.parse_args()
     variants = [('tile', 0, 0), ('pp256', 2, 0), ('pp128', 3, 0), ('auto', 1, 0)]
+    if args.scheds:
+        variants = [('tile', 0, 0)] + [(f'pp{args.bm}/s{n}', 2 if args.bm == 256 else 3, int(n))
+                                       for n in args.scheds.split(',')]
+        if not args.bpack and any(v[2] >= 16 for v in variants):
+            raise SystemExit('schedules >= 16 read a packed B operand: add --bpack')
     print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
-    print(f'{"shape":44s} {"n":>3s} ' + ' '.join(f'{v[0]:>8s}' for v in variants) + '   best TF/s  speedup  fwd-ms tile -> best')
+    print(f'{"shape":44s} {"n":>3s} ' + ' '.join(f'{v[0]:>9s}' for v in variants) + '   best TF/s  speedup  fwd-ms tile -> best')
     tot_old = tot_best = 0.0
     for kind, name, a, count in shapes(args.batch):
+        torch.manual_seed(0)
         fn, flop = make(kind, a)
+        fns = {v[0]: fn for v in variants}
+        if args.bpack:
+            torch.manual_seed(0)                # same operands, B piece-major
+            fn_packed, _ = make(kind, a, packed=True)
+            fns.update({v[0]: fn_packed for v in variants if v[2] >= 16})
         ts = {v[0]: [] for v in variants}
+        outs = {}
         for v in variants:                      # warm every variant (first launch sets the LDS attribute)
             ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2])
-            fn()
+            outs[v[0]] = fns[v[0]]()
         torch.cuda.synchronize()
+        bad = [k for k, o in outs.items() if not torch.equal(o, outs['tile'])]
+        if bad:
+            print(f'# {name}: variants differing from the tile kernels: {bad}')
+        del outs
         for _ in range(args.rounds):
             for v in variants:
                 ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2])
-                ts[v[0]].append(time_once(fn, args.reps))
+                ts[v[0]].append(time_once(fns[v[0]], args.reps))
         med = {k: sorted(x)[len(x) // 2] * 1000.0 for k, x in ts.items()}
         best = min(med, key=med.get)
         tot_old += med['tile'] * count / 1000.0
         tot_best += med[best] * count / 1000.0
-        print(f'{name:44s} {count:3d} ' + ' '.join(f'{med[v[0]]:8.1f}' for v in variants) +
-              f'   {flop / med[best] / 1e6:7.1f}  {med["tile"] / med[best]:6.2f}x  {best:6s}'
+        print(f'{name:44s} {count:3d} ' + ' '.join(f'{med[v[0]]:9.1f}' for v in variants) +
+              f'   {flop / med[best] / 1e6:7.1f}  {med["tile"] / med[best]:6.2f}x  {best:9s}'
               f' {med["tile"] * count / 1000:6.2f} -> {med[best] * count / 1000:6.2f}', flush=True)
     ops.set_option('gemm_pp', 1); ops.set_option('pp_sched', 0)
     print(f'# GEMM time per forward (listed shapes): tile kernels {tot_old:.2f} ms, best-of {tot_best:.2f} ms')

@@ -8,7 +8,10 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so')
+# VSX_LIB_VARIANT=next: the development build of videoswap_amd/build.py's VARIANTS (kernel candidates that are A/B-ed
+# against the measured library before they replace it); unset = the product's libvsx.so
+VARIANT = os.environ.get('VSX_LIB_VARIANT') or None
+LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so' if not VARIANT else f'libvsx_{VARIANT}.so')
 
 VSX_ABI_VERSION = 4
 
@@ -113,7 +116,7 @@ def load():
     csrc = os.path.join(_HERE, 'csrc')
     if os.path.isdir(csrc) and not os.environ.get('VSX_SKIP_DIGEST_CHECK'):
         from .build import source_digest
-        have, want = lib.vsx_source_digest().decode(), source_digest()
+        have, want = lib.vsx_source_digest().decode(), source_digest(VARIANT)
         if have != want:
             raise VsxError(f'libvsx.so was built from different sources (digest {have[:12]} != {want[:12]}); '
                            f'rebuild it with `python -m videoswap_amd.build` (VSX_SKIP_DIGEST_CHECK=1 overrides)')

@@ -1,9 +1,14 @@
 """Build libvsx.so (hand-written HIP kernels for gfx950) in-tree with hipcc.
 
-    python -m videoswap_amd.build [--force]
+    python -m videoswap_amd.build [--force] [--variant next]
 
 hipcc cross-compiles for gfx950 without a GPU.  The shared library lands in videoswap_amd/lib/
 (git-ignored, but it travels with the gpurun snapshot).
+
+Variants: `--variant next` builds lib/libvsx_next.so from the same sources with the files listed in VARIANTS swapped
+for their csrc/experimental/ versions — kernels under development that have not been measured yet.  The product loads
+libvsx.so; `VSX_LIB_VARIANT=next` makes `videoswap_amd._lib` load the variant instead (tools/gemm_ab.py and the kernel
+tests then run against it), so that a candidate can be A/B-ed on the GPU without touching the measured library.
 """
 import hashlib
 import os
@@ -17,6 +22,8 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIB = os.path.join(LIBDIR, 'libvsx.so')
+# variant name -> {source file of SOURCES: replacement, relative to csrc/}
+VARIANTS = {'next': {'gemm_pp.hip': 'experimental/gemm_pp.hip'}}
 SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
@@ -26,40 +33,51 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
          '-mllvm', '-amdgpu-mfma-vgpr-form']
 
 
-def _digest():
+def lib_path(variant=None):
+    return LIB if not variant else os.path.join(LIBDIR, f'libvsx_{variant}.so')
+
+
+def _digest(variant=None):
     """sha256 over the kernel sources, the public header and the compiler flags.  Location-independent: the flags
-    are hashed with the checkout path stripped (the gpurun snapshot lives under another root than the build tree)."""
+    are hashed with the checkout path stripped (the gpurun snapshot lives under another root than the build tree).
+    A variant hashes its replacement files in place of the ones they replace (and its name)."""
     h = hashlib.sha256()
+    swap = VARIANTS[variant] if variant else {}
     names = [n for n in sorted(os.listdir(CSRC)) if n.endswith(('.hip', '.cpp', '.h'))]
     for name in names + ['../../include/vsx.h']:
-        with open(os.path.join(CSRC, name), 'rb') as f:
+        with open(os.path.join(CSRC, swap.get(name, name)), 'rb') as f:
             h.update(name.encode() + b'\0' + f.read())
     h.update(' '.join(f.replace(ROOT, '<root>') for f in FLAGS).encode())
+    if variant:
+        h.update(b'\0variant ' + variant.encode())
     return h.hexdigest()
 
 
-def source_digest():
+def source_digest(variant=None):
     """Digest of everything libvsx.so is built from; embedded in the binary (vsx_source_digest)."""
-    return _digest()
+    return _digest(variant)
 
 
-def built_digest():
+def built_digest(variant=None):
     """Digest embedded in the existing libvsx.so, or None (missing / predates the symbol)."""
-    if not os.path.exists(LIB):
+    if not os.path.exists(lib_path(variant)):
         return None
     import ctypes
     try:
-        fn = ctypes.CDLL(LIB).vsx_source_digest
+        fn = ctypes.CDLL(lib_path(variant)).vsx_source_digest
     except (OSError, AttributeError):
         return None
     fn.restype = ctypes.c_char_p
     return fn().decode()
 
 
-def _compile(src, digest):
-    obj = os.path.join(OBJDIR, src + '.o')
+def _compile(src, digest, variant=None):
+    objdir = OBJDIR if not variant else os.path.join(LIBDIR, f'obj_{variant}')
+    os.makedirs(objdir, exist_ok=True)
+    obj = os.path.join(objdir, src + '.o')
     extra = [f'-DVSX_SOURCE_DIGEST="{digest}"'] if src == 'api.cpp' else []
-    cmd = [HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+    path = os.path.join(CSRC, (VARIANTS[variant] if variant else {}).get(src, src))
+    cmd = [HIPCC] + FLAGS + extra + ['-c', path, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
@@ -68,26 +86,28 @@ def _compile(src, digest):
     return obj
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, variant=None):
     os.makedirs(OBJDIR, exist_ok=True)
-    digest = _digest()
+    lib = lib_path(variant)
+    digest = _digest(variant)
     # the digest lives INSIDE the binary (no side-car stamp file that git could update without the .so)
-    if not force and built_digest() == digest:
+    if not force and built_digest(variant) == digest:
         if verbose:
-            print(f'[vsx] {LIB} is up to date')
-        return LIB
+            print(f'[vsx] {lib} is up to date')
+        return lib
     if not os.path.exists(HIPCC):
-        raise RuntimeError(f'{HIPCC} not found: cannot build libvsx.so')
+        raise RuntimeError(f'{HIPCC} not found: cannot build {os.path.basename(lib)}')
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(lambda src: _compile(src, digest), SOURCES))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
+        objs = list(ex.map(lambda src: _compile(src, digest, variant), SOURCES))
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + ['-ldl']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
     if verbose:
-        print(f'[vsx] built {LIB}')
-    return LIB
+        print(f'[vsx] built {lib}')
+    return lib
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    _variant = sys.argv[sys.argv.index('--variant') + 1] if '--variant' in sys.argv else None
+    build(force='--force' in sys.argv, variant=_variant)

@@ -1,0 +1,651 @@
+// DEVELOPMENT VARIANT of ../gemm_pp.hip (library variant "next", videoswap_amd/build.py VARIANTS; NOT part of the
+// measured libvsx.so).  Difference to the shipped file: the DMA pieces of the next slab can also be issued INSIDE the
+// MFMA phases, between the MFMAs of the same wave (piece schedules 3..6 of option "pp_sched"; 0..2 reproduce the
+// shipped load-phase-only schedules instruction for instruction).  Why: profiles/r02_pmc_sq.txt + the phase model in
+// DESIGN.md §3.1 — a load phase is ~560 cycles (the group's four waves queue 2-3 pieces each on the CU's one
+// address path, ~150 cycles per piece when contended) against 320 cycles of MFMA in the partner's phase, so the
+// matrix pipe idles ~45 % of the main loop.  A piece issued between two MFMAs of a wave whose partner group is only
+// reading fragments meets an idle address path (~30-80 cycles): moving 1-2 of the 2-3 pieces per k-step there
+// should balance the two phases at ~350-400 cycles.  Arithmetic is untouched (same MFMAs, same k order): results stay
+// bit-identical to the tile kernels — tests/test_kernels_gpu.py::test_persistent_* with VSX_LIB_VARIANT=next.
+// Second experiment (pp_sched + 16): the B operand pre-packed piece-major ([N/8][K/64][8 rows][64 halfs]: every 1-KiB
+// DMA piece is one contiguous KiB).  tools/ubench/l2_delivery measured 60 B/clk/CU for contiguous 1-KiB pieces against
+// 30-40 for eight 128-byte row segments; the weights are 40 of a slab's 72 pieces.  The host packs the weight once
+// (tools/gemm_ab.py --bpack); needs K % 64 == 0.
+//
+// K1/K2 (big problems) — persistent "ping-pong" fp16 MFMA GEMM / implicit-GEMM convolution for gfx950.
+//
+// Same contract, operand staging (LDS-DMA with buffer descriptors, 128-byte-row K slabs of 64 halfs, XOR-swizzled LDS
+// rows, implicit im2col / stride / nearest-2x / two-source A loader) and epilogue arithmetic as gemm.hip; what differs
+// is the work decomposition and the main-loop schedule, both chosen from the measurements of the
+// workgroup-per-tile kernel (profiles/r01_*):
+//
+//  * 8 waves (2 per SIMD), each owning a (TM*32) x 160 block of the 256x320 (TM = 2) or 128x320 (TM = 1) tile:
+//    with 64x160 per wave a k-step reads 7 KiB of fragments for 10 MFMAs (the 16-wave 32x160 layout read 6 KiB for
+//    5): the tile's LDS read traffic drops from 384 to 224 KiB per slab, and the 160 accumulator registers fit the
+//    256-register budget of 2 waves per SIMD.
+//  * PING-PONG: the workgroup is two groups of four waves (one wave of each group per SIMD).  Every k-step is a
+//    LOAD phase (fragment ds_reads for that k-step + this wave's share of the next slab's LDS-DMA pieces) followed
+//    by an MFMA phase (10 back-to-back MFMAs), with one s_barrier after every phase.  Group 1 runs one phase behind
+//    group 0, so at any time one wave of a SIMD feeds the matrix pipe while its partner does everything else; the
+//    DMA-issue stalls (a 1-KiB piece blocks its wave for 60-180 cycles) and the LDS latency never sit in front of an
+//    MFMA of the same wave.
+//  * PERSISTENT: one workgroup per CU walks its XCD's contiguous range of output tiles; the operand stream (slabs
+//    in order: tile after tile) runs one slab ahead of the MFMAs ACROSS tile boundaries, so the first slab of the
+//    next tile lands under the epilogue of the current one.  K = 320 problems (five slabs per tile) no longer pay a
+//    cold prologue per tile.
+//
+// Phase timeline (|B| = workgroup barrier; L/M = load / MFMA phase of k-step s of slab t):
+//     G0:  L0 |B| M0 |B| L1 |B| M1 |B| L2 |B| M2 |B| L3 |B| M3 |B| L0' ...
+//     G1:     |B| L0 |B| M0 |B| L1 |B| M1 |B| L2 |B| M2 |B| L3 |B| M3  ...
+// Ring of two slabs.  Slab t+1 is written into the slot slab t-1 occupied; its last reader is G1's L3(t-1), which
+// has waited for its ds_reads (lgkmcnt(0)) before the barrier that precedes G0's L0(t), the first phase that issues
+// a piece of slab t+1.  Every wave waits for its own pieces (vmcnt(0)) before the barrier that precedes G0's L0(t+1):
+// G0 at the end of M3(t), G1 at the end of L3(t).
+// At a tile boundary both groups run the epilogue in the SAME barrier interval and then resynchronise
+// (G0: |B| E |B| L0' |B| ..., G1: M3 E |B| |B| L0' ...).
+//
+// Register budget (256 per lane, nothing may spill: a scratch reload is a VMEM op and would queue behind the DMA
+// pieces in flight): 160 accumulators + 28 fragment registers; row offsets are NOT kept per piece — a piece's row base
+// is wave-uniform and travels in the scalar offset of the buffer load, the lane keeps only (row-in-piece, k-slot)
+// offsets; the launch parameters are read from the kernarg segment where they are used (s_load) instead of living
+// in SGPRs across the tile loop.
+#include "gemm_common.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace vsxg {
+namespace {
+
+typedef const __attribute__((address_space(4))) GemmParams* kparams_t;
+
+__device__ __forceinline__ kparams_t kernarg_params() {
+    kparams_t kp = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();   // GemmParams is the first kernel argument
+    asm volatile("" : "+s"(kp));                 // opaque: fields are (re)loaded where they are used
+    return kp;
+}
+
+// Epilogue of one wave: TM x 5 C^T accumulator tiles (acc[j][i]: lane (l31, hi) owns output row mrow0 + i*32 + l31;
+// register quad g of tile (j, i) holds the 4 consecutive columns ncol0 + j*32 + 8g + 4hi ..).
+//
+// Writing C straight from that layout costs more than the main loop of a K <= 1280 problem: every store instruction
+// touches 32 different rows with 2 x 16 bytes each (64 partial lines; measured 4.5 B/clk/CU, 36 k cycles per 256x320
+// tile against 13 k for its five K slabs), and the residual is read the same way.  So the tile goes through a
+// wave-private LDS staging area (fp32, 32 rows x 64 columns at a time, rows padded by 16 B: conflict-free
+// ds_write_b128 from the fragment layout) and is read back ROW-MAJOR: a lane then owns 8 consecutive columns of one
+// row, 8 lanes cover one full 128-byte line, and bias / row vector / residual are added in that layout — same
+// fp32 operation order as gemm.hip's epilogue, so the results stay bit-identical to the tile kernels.
+// The host routes a problem here only when every row / column octet is 16-byte aligned and N is a multiple of 160
+// (GEGLU) / 320, so there is no column edge; rows >= M are skipped.
+constexpr int EP_BYTES = 10240;     // staging bytes per wave: 32 rows x (64 + 4) floats = 8704
+
+template <int CW>                   // chunk width in output columns: 64, 32 or 16
+__device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, const int lane, const int mblk,
+                                              const int ncol, const bool add_bias) {
+    constexpr int STRIDE = CW + 4;                  // floats per staged row
+    constexpr int LPR = CW / 8;                     // lanes per row (8 columns each)
+    constexpr int RPP = 64 / LPR;                   // rows per pass
+    const int Mi = (int)p->M, Ni = (int)p->N;
+    const int col8 = (lane % LPR) * 8, r0 = lane / LPR;
+    const int n = ncol + col8;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (add_bias && p->bias) {
+        const h8 b = *reinterpret_cast<const h8*>(p->bias + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = (float)b[e];
+    }
+    const half_t* rvp = p->rowvec;
+    const half_t* resp = p->residual;
+    half_t* cp = p->C;
+    const unsigned ldc = (unsigned)p->ldc, ldr = (unsigned)p->ldr, rpv = (unsigned)p->rows_per_vec;
+#pragma unroll
+    for (int pass = 0; pass < 32 / RPP; ++pass) {
+        const int row = pass * RPP + r0;
+        const int m = mblk + row;
+        if (m >= Mi) continue;
+        const f4v a = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8);
+        const f4v b = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8 + 4);
+        float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (add_bias && p->bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += bv[e];
+        }
+        if (rvp) {
+            const h8 v = *reinterpret_cast<const h8*>(rvp + ((unsigned)m / rpv) * (unsigned)Ni + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += (float)v[e];
+        }
+        if (resp) {
+            const h8 v = *reinterpret_cast<const h8*>(resp + (unsigned)m * ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += (float)v[e];
+        }
+        h8 pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk[e] = (half_t)o[e];
+        *reinterpret_cast<h8*>(cp + (unsigned)m * ldc + n) = pk;
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, const int mrow0, const int ncol0,
+                                            const int gcol0, const int lane) {
+    kparams_t p = kernarg_params();
+    const int l31 = lane & 31, hi = lane >> 5;
+    const float alpha = p->alpha;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mblk = mrow0 + i * 32;
+        if (p->geglu) {
+            // tile j: registers 0-7 are h of 16 output columns, registers 8-15 the matching g.  The activation (which
+            // needs the bias first) is computed in the fragment layout; chunks: j = 0..3 (64 columns), j = 4 (16)
+            const half_t* bias = p->bias;
+            const int Ni = (int)p->N;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int j0 = c * 4, nj = c ? 1 : 4;
+                const int stride = nj * 16 + 4;
+#pragma unroll
+                for (int jj = 0; jj < nj; ++jj) {
+                    const int j = j0 + jj;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int nb = gcol0 + j * 16 + 8 * q + 4 * hi;
+                        float hv[4], gv[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            hv[e] = acc[j][i][4 * q + e] * alpha;
+                            gv[e] = acc[j][i][8 + 4 * q + e] * alpha;
+                        }
+                        if (bias) {
+                            const h4 bh = *reinterpret_cast<const h4*>(bias + nb);
+                            const h4 bg = *reinterpret_cast<const h4*>(bias + Ni + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { hv[e] += (float)bh[e]; gv[e] += (float)bg[e]; }
+                        }
+                        f4v o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
+                        *reinterpret_cast<f4v*>(stg + l31 * stride + jj * 16 + 8 * q + 4 * hi) = o;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one accumulator tile at a time (register pressure)
+                }
+                if (c == 0) epilogue_rows<64>(p, stg, lane, mblk, gcol0, false);
+                else epilogue_rows<16>(p, stg, lane, mblk, gcol0 + 64, false);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
+        }
+        // plain: chunks j = {0, 1}, {2, 3} (64 columns: one full 128-byte line per row), {4} (32 columns)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int j0 = c * 2, nj = c < 2 ? 2 : 1;
+            const int stride = nj * 32 + 4;
+#pragma unroll
+            for (int jj = 0; jj < nj; ++jj) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f4v o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[j0 + jj][i][4 * g + e] * alpha;
+                    *reinterpret_cast<f4v*>(stg + l31 * stride + jj * 32 + 8 * g + 4 * hi) = o;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c < 2) epilogue_rows<64>(p, stg, lane, mblk, ncol0 + j0 * 32, true);
+            else epilogue_rows<32>(p, stg, lane, mblk, ncol0 + j0 * 32, true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Piece schedule: how many of this wave's 2*TM + 5 DMA pieces of the next slab are issued in each of the six slots
+// L0 M0 L1 M1 L2 M2 (load / MFMA phases of k-steps 0..2; A pieces first: they come from HBM / Infinity Cache, the
+// weights from L2).  L3 / M3 issue nothing: group 1 must have its pieces landed at the end of its L3, group 0 at the
+// end of its M3.  Row s of the table = option pp_sched = s; columns = pieces per slot for 9 (TM = 2) and 7 (TM = 1).
+struct Sched { int n9[6]; int n7[6]; };
+constexpr Sched SCHEDS[] = {
+    {{3, 0, 3, 0, 3, 0}, {3, 0, 2, 0, 2, 0}},      // 0: the shipped default (load phases only)
+    {{4, 0, 3, 0, 2, 0}, {3, 0, 3, 0, 1, 0}},      // 1
+    {{5, 0, 4, 0, 0, 0}, {4, 0, 3, 0, 0, 0}},      // 2
+    {{2, 1, 2, 1, 2, 1}, {2, 1, 1, 1, 1, 1}},      // 3: one piece per MFMA phase
+    {{1, 2, 1, 2, 1, 2}, {1, 1, 1, 1, 1, 2}},      // 4: two pieces per MFMA phase
+    {{0, 3, 0, 3, 0, 3}, {0, 3, 0, 2, 0, 2}},      // 5: MFMA phases only
+    {{2, 2, 2, 2, 1, 0}, {2, 2, 2, 1, 0, 0}},      // 6: front-loaded mix (the last pieces land well before the waits)
+};
+constexpr int NSCHED = sizeof(SCHEDS) / sizeof(SCHEDS[0]);
+
+constexpr int sched_end(const int sched, const int npiece, const int slot) {     // pieces issued in slots 0..slot
+    int e = 0;
+    for (int s = 0; s <= slot; ++s) e += npiece == 9 ? SCHEDS[sched].n9[s] : SCHEDS[sched].n7[s];
+    return e;
+}
+
+// TM: 32-row blocks per wave (tile = 128*TM x 320).  CONV: implicit-GEMM A loader (a_mode 1) or plain row-major A.
+// BPACK: B is stored piece-major (see the header); else row-major [N, ldb].
+template <int TM, bool CONV, int SCHED, bool BPACK>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused, const int tiles_total) {
+    constexpr int TN = 5;
+    constexpr int BM = 128 * TM, BN = 320;
+    constexpr int WM = 32 * TM, WN = 160;
+    constexpr int GA = 2 * TM;                  // 8-row (1 KiB) A pieces per wave and slab
+    constexpr int GB = 5;                       // B pieces per wave and slab
+    constexpr int NPIECE = GA + GB;
+    static_assert(NPIECE == 9 || NPIECE == 7, "schedule tables cover 9 and 7 pieces");
+    constexpr int E0 = sched_end(SCHED, NPIECE, 0), E1 = sched_end(SCHED, NPIECE, 1), E2 = sched_end(SCHED, NPIECE, 2),
+                  E3 = sched_end(SCHED, NPIECE, 3), E4 = sched_end(SCHED, NPIECE, 4), E5 = sched_end(SCHED, NPIECE, 5);
+    static_assert(E5 == NPIECE, "a schedule must issue every piece");
+    constexpr int STAGE = (BM + BN) * 128;      // bytes per ring slot
+    constexpr int NFIT = STAGE / EP_BYTES;      // waves whose epilogue staging area fits a ring slot
+    constexpr int OOB_OFF = (int)0x80000000;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    kparams_t p = kernarg_params();
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int G = wave >> 2;                    // ping-pong group: waves w and w + 4 share a SIMD
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- this workgroup's tiles: XCD x (workgroups b with b % 8 == x) owns a contiguous range of the
+    // (tile_m, tile_n) space — its CUs share one L2 — and the XCD's workgroups stride through it together ----
+    const int nwg = gridDim.x;
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int q8 = tiles_total >> 3, r8 = tiles_total & 7;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int wgx = (nwg - xcd + 7) >> 3;       // workgroups placed on this XCD
+    const int n_my = local < cnt ? (cnt - local + wgx - 1) / wgx : 0;
+    if (n_my == 0) return;
+    const int tile0 = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + local;   // + k * wgx
+
+    // ---- LDS-DMA coordinates (see gemm.hip): lane -> (row lrow of an 8-row piece, physical 16-byte slot pslot);
+    // the XOR swizzle slot ^= (tile_row >> 1) & 7 is applied to the SOURCE column ----
+    const int lrow = lane >> 3;
+    const int pslot = lane & 7;
+    const int kofs_e = (pslot ^ (lrow >> 1)) * 8;           // even pieces
+    const int kofs_o = (pslot ^ (4 | (lrow >> 1))) * 8;     // odd pieces
+
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p->A), 0, (int)p->a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p->B), 0, (int)p->b_bytes, 0x00020000);
+    // second conv source (skip concat): built here, not where it is used — an s_load in a load phase would put an
+    // lgkmcnt(0) (and with it the fragment ds_reads) in front of the DMA issue
+    const __amdgpu_buffer_rsrc_t rsrcA2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(CONV && p->A2 ? p->A2 : p->A), 0, (int)(CONV ? p->a2_bytes : 0u), 0x00020000);
+
+    const int Mi = (int)p->M;
+    const int tiles_n = p->tiles_n;
+    const int geglu = p->geglu;
+    const int K = (int)p->K;
+    const int nk = (K + BK - 1) / BK;
+    const int ktail_from = K - (nk - 1) * BK;            // last slab: k offsets >= this are beyond K
+    const unsigned lda2 = (unsigned)p->lda * 2u, ldb2 = (unsigned)p->ldb * 2u;   // row pitches in bytes
+    const int w5 = wave * GB;                    // this wave's first B piece
+    const int Ngeglu = (int)p->N;
+
+    // per-lane parts of the operand offsets (bytes): row-in-piece * pitch + swizzled k slot
+    const int vb_e = (int)((unsigned)lrow * (BPACK ? 128u : ldb2)) + kofs_e * 2;
+    const int vb_o = (int)((unsigned)lrow * (BPACK ? 128u : ldb2)) + kofs_o * 2;
+    const unsigned bgrp = (unsigned)nk * 1024u;             // BPACK: bytes of one 8-row group (nk pieces)
+    int va_e = 0, va_o = 0;                      // plain A
+    int va[CONV ? GA : 1];                       // conv A: pixel offsets of this lane's row in each of its pieces
+    int a_hw[CONV ? GA : 1], a_ib[CONV ? GA : 1];   // conv: (h0 + 4) | (w0 + 4) << 16 (h0 = -4: row >= M), image base
+    if constexpr (!CONV) {
+        va_e = (int)((unsigned)lrow * lda2) + kofs_e * 2;
+        va_o = (int)((unsigned)lrow * lda2) + kofs_o * 2;
+    }
+
+    // ---- issue side: the operand stream (tile after tile, slab after slab), one slab ahead of the MFMAs ----
+    int i_t = 0, i_kt = 0, i_g = 0;              // tile (index into my sequence), slab in tile, slabs issued so far
+    bool need_setup = true;
+    int t_kh = 0, t_kw = 0, t_c = 0;             // conv: filter tap / channel base of the next slab
+    bool t_second = false, t_dirty = true;
+    int i_m0 = 0;                                // first row of the tile being staged
+    unsigned i_rowB = 0;                         // (first B row of the tile) * pitch
+
+    auto tile_setup = [&](const int tile) {
+        const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+        i_m0 = tile_m * BM;
+        i_rowB = BPACK ? (unsigned)((geglu ? tile_n * (BN / 2) : tile_n * BN) >> 3) * bgrp
+                       : (unsigned)(geglu ? tile_n * (BN / 2) : tile_n * BN) * ldb2;
+        if constexpr (CONV) {
+            const unsigned Wo = (unsigned)p->Wo, hw = (unsigned)p->Ho * Wo;
+            const int stride = p->stride, pad = p->pad;
+            const int Hs = p->ups ? (p->H >> 1) : p->H;
+#pragma unroll
+            for (int i = 0; i < GA; ++i) {
+                const int m = i_m0 + (wave * GA + i) * 8 + lrow;
+                const unsigned mm = m < Mi ? (unsigned)m : 0u;
+                const unsigned img = mm / hw;
+                const unsigned rem = mm - img * hw;
+                const unsigned ho = rem / Wo;
+                const int h0 = m < Mi ? (int)ho * stride - pad : -4;        // -4 + any tap < 0: never in range
+                const int w0 = (int)(rem - ho * Wo) * stride - pad;
+                a_hw[i] = (h0 + 4) | ((w0 + 4) << 16);
+                a_ib[i] = (int)img * Hs;
+            }
+            t_kh = 0; t_kw = 0; t_c = 0; t_second = false; t_dirty = true;
+        }
+    };
+
+    int i_sb = 0;                                // LDS byte offset of the slot being filled
+    bool i_tail = false, i_second = false, i_on = true;
+    unsigned i_soffA = 0, i_soffB = 0;
+    auto slab_prep = [&]() {                    // fixes the offsets of stream slab i_g and advances the stream
+        if (need_setup) {
+            tile_setup(tile0 + i_t * wgx);
+            need_setup = false;
+        }
+        const int kt = i_kt;
+        if constexpr (CONV) {
+            const int C1 = p->C1, C2 = p->C2, ks = p->ks;
+            if (t_dirty) {                      // a slab never straddles a filter tap or the two concatenated sources
+                const int csz = t_second ? C2 : C1;
+                const int H = p->H, W = p->W, ups = p->ups;
+                const int Ws = ups ? (W >> 1) : W;
+#pragma unroll
+                for (int i = 0; i < GA; ++i) {
+                    const int hh = (a_hw[i] & 0xffff) - 4 + t_kh, ww = (a_hw[i] >> 16) - 4 + t_kw;
+                    const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+                    const int hsrc = ups ? (hh >> 1) : hh, wsrc = ups ? (ww >> 1) : ww;
+                    const int kofs = (i & 1) ? kofs_o : kofs_e;
+                    va[i] = ok ? (((a_ib[i] + hsrc) * Ws + wsrc) * csz + kofs) * 2 : OOB_OFF;
+                }
+                t_dirty = false;
+            }
+            i_second = t_second;
+            i_soffA = (unsigned)t_c * 2u;
+            t_c += BK;
+            if (t_c >= (t_second ? C2 : C1)) {          // next source or next tap
+                t_c = 0;
+                t_dirty = true;
+                if (!t_second && C2 > 0) {
+                    t_second = true;
+                } else {
+                    t_second = false;
+                    if (++t_kw == ks) { t_kw = 0; ++t_kh; }
+                }
+            }
+        } else {
+            i_soffA = (unsigned)(i_m0 + wave * GA * 8) * lda2 + (unsigned)kt * (BK * 2);
+        }
+        i_soffB = i_rowB + (unsigned)kt * (BPACK ? 1024u : (unsigned)(BK * 2));
+        i_sb = (i_g & 1) * STAGE;
+        i_tail = (kt == nk - 1) && ktail_from < BK;
+        ++i_g;
+        if (++i_kt == nk) { i_kt = 0; ++i_t; need_setup = true; }
+    };
+    auto issue_piece = [&](const int q) {           // q is a compile-time constant at every call site
+        if (q < GA) {
+            const int kofs = (q & 1) ? kofs_o : kofs_e;             // wave * GA is even
+            lptr_t dst = (lptr_t)(smem + i_sb + (wave * GA + q) * 1024);
+            if constexpr (CONV) {
+                const int v = (i_tail && kofs >= ktail_from) ? OOB_OFF : va[q < GA ? q : 0];
+                if (i_second) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, dst, 16, v, (int)i_soffA, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, (int)i_soffA, 0, 0);
+                }
+            } else {
+                const bool ok = (i_m0 + (wave * GA + q) * 8 + lrow < Mi) && !(i_tail && kofs >= ktail_from);
+                const int v = ok ? ((q & 1) ? va_o : va_e) : OOB_OFF;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, (int)(i_soffA + (unsigned)(q * 8) * lda2),
+                                                         0, 0);
+            }
+        } else {
+            const int j = q - GA;
+            const int pj = w5 + j;                                   // piece index inside the 320-row B tile
+            const bool odd = (pj & 1) != 0;
+            const int kofs = odd ? kofs_o : kofs_e;
+            // row of the weight matrix behind tile row pj*8 + lrow: plain n0 + pj*8 + lrow; GEGLU interleaves h and g
+            // rows 16 + 16 inside every 32-row MFMA tile (rows 0-15 = h columns, 16-31 = the matching g columns)
+            const unsigned srow = geglu ? (unsigned)((pj >> 2) * 16 + (pj & 1) * 8 + ((pj >> 1) & 1) * Ngeglu)
+                                        : (unsigned)(pj * 8);
+            const int v = (i_tail && kofs >= ktail_from) ? OOB_OFF : (odd ? vb_o : vb_e);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(smem + i_sb + BM * 128 + pj * 1024), 16, v,
+                                                     (int)(i_soffB + (BPACK ? (srow >> 3) * bgrp : srow * ldb2)), 0, 0);
+        }
+    };
+    auto issue_range = [&](const int lo, const int hi_) {   // compile-time bounds at every call site
+        if (!i_on) return;
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q)
+            if (q >= lo && q < hi_) issue_piece(q);
+    };
+
+    f16v acc[TN][TM];
+    // fragment addresses: row (.. + l31) * 128 B, logical 16-byte slot ks*2 + hi, swizzled by (row >> 1) & 7:
+    // ((ks*2 + hi) ^ swz) * 16 = ((hi ^ swz) * 16) ^ (ks * 32), and the row bases are multiples of 128
+    const int fr = ((hi ^ ((l31 >> 1) & 7)) * 16);
+    const int a_addr = (wr * WM + l31) * 128 + fr;
+    const int b_addr = BM * 128 + (wc * WN + l31) * 128 + fr;
+
+    h8 af[TM], bf[TN];
+    auto ldfrag = [&](const int slot_off, const int ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[i] = *reinterpret_cast<const h8*>(smem + slot_off + ((a_addr ^ (ks * 32)) + i * 4096));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            bf[j] = *reinterpret_cast<const h8*>(smem + slot_off + ((b_addr ^ (ks * 32)) + j * 4096));
+    };
+    auto mma = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[j][i], 0, 0, 0);
+    };
+    auto mma_first = [&]() {                    // first k-step of a tile: C = 0 (inline constant, no zero-fill pass)
+        const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], zero, 0, 0, 0);
+    };
+    // MFMA phase that also issues pieces [lo, hi_) of the next slab: piece k of the n goes behind MFMA number
+    // (k + 1) * NM / (n + 1) - 1 (evenly spread, never behind the last one), pinned there by scheduling barriers
+    auto mma_issue = [&](auto first_tag, const int lo, const int hi_) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int NM = TM * TN;
+        const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int n = hi_ - lo;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int i = m / TN, j = m % TN;
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], FIRST ? zero : acc[j][i], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q)
+                if (q >= lo && q < hi_ && ((q - lo + 1) * NM) / (n + 1) - 1 == m) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i_on) issue_piece(q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+    };
+    auto mma_phase = [&](const bool first, const int lo, const int hi_) {       // lo == hi_: the plain MFMA phase
+        if (lo == hi_) {
+            if (first) mma_first(); else mma();
+        } else {
+            if (first) mma_issue(std::true_type{}, lo, hi_); else mma_issue(std::false_type{}, lo, hi_);
+        }
+    };
+    auto lgkm0 = [&]() { __builtin_amdgcn_s_waitcnt(0xC07F); };     // lgkmcnt(0)
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- prologue: slab 0 of the first tile, all pieces at once ----
+    slab_prep();
+    issue_range(0, NPIECE);
+    wait_vmcnt<0>();
+    bar();
+    if (G == 1) bar();                          // group 1 runs one phase behind
+
+    int c_g = 0;
+    for (int c_t = 0; c_t < n_my; ++c_t) {
+        for (int kt = 0; kt < nk; ++kt, ++c_g) {
+            const int so = (c_g & 1) * STAGE;
+            i_on = i_t < n_my;
+            if (i_on) slab_prep();              // the slab that streams in while this one is multiplied
+            // ---- k-step 0 ----
+            ldfrag(so, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_range(0, E0);
+            lgkm0();
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mma_phase(kt == 0, E0, E1);
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+            // ---- k-step 1 ----
+            ldfrag(so, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_range(E1, E2);
+            lgkm0();
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mma_phase(false, E2, E3);
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+            // ---- k-step 2 ----
+            ldfrag(so, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_range(E3, E4);
+            lgkm0();
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mma_phase(false, E4, E5);
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+            // ---- k-step 3 ----
+            ldfrag(so, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (G == 1) wait_vmcnt<0>();        // G1's pieces of the next slab (issued in its L0..L2) have landed
+            lgkm0();
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mma();
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (G == 0) wait_vmcnt<0>();        // G0's pieces: waited behind its last MFMAs
+            if (kt + 1 < nk) bar();
+        }
+        // ---- tile boundary: both groups run the epilogue in the same barrier interval (G0: |B| E, G1: M3 E), then
+        // meet at a barrier — the epilogue stages C through the ring slot the tile's last slab occupied (waves
+        // 0..NFIT-1) and the LDS behind the ring (the others), and G0's next load phase issues DMA into that slot —
+        // and G1 drops one phase behind again.  (The other slot holds slab 0 of the next tile, already landed.) ----
+        if (G == 0) bar();
+        {
+            const int tile = tile0 + c_t * wgx;
+            const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+            const int n0 = geglu ? tile_n * (BN / 2) : tile_n * BN;
+            const int stg_off = wave < NFIT ? ((c_g - 1) & 1) * STAGE + wave * EP_BYTES
+                                            : 2 * STAGE + (wave - NFIT) * EP_BYTES;
+            epilogue_pp<TM>(acc, reinterpret_cast<float*>(smem + stg_off), tile_m * BM + wr * WM, n0 + wc * WN,
+                            n0 + wc * TN * 16, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lgkm0();
+        bar();
+        if (G == 1) bar();
+    }
+    if (G == 0) bar();                          // matches group 1's extra barrier at the start
+}
+
+template <int TM, bool CONV, int SCHED, bool BPACK = false>
+int launch_one(const GemmParams& p, hipStream_t stream) {
+    constexpr size_t stage = (size_t)(128 * TM + 320) * 128;
+    constexpr size_t smem = 2 * stage + (8 - stage / EP_BYTES) * EP_BYTES;     // ring + the staging areas behind it
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TM, CONV, SCHED, BPACK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return vsx_fail(VSX_E_LAUNCH, "gemm_pp: cannot query the device");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = p.tiles_total < n_cu ? p.tiles_total : n_cu;      // one persistent workgroup per CU
+    hipLaunchKernelGGL((gemm_pp_kernel<TM, CONV, SCHED, BPACK>), dim3((unsigned)grid), dim3(512), smem, stream, p,
+                       p.tiles_total);
+    return vsx_check_launch("vsx_gemm_f16 (persistent)");
+}
+
+}  // namespace
+
+bool pp_supported(const GemmParams& p) {
+    // no column edge (N a multiple of the tile), 16-byte epilogue accesses, fast-tap convolutions, 32-bit offsets
+    const long cols = p.geglu ? 2 * p.N : p.N;
+    if (cols % 320 != 0 || p.c_mode != 0 || p.splitk > 1) return false;
+    if (!p.vec8 || (p.residual && !p.rvec8)) return false;
+    if (!vsx_aligned16(p.bias) || !vsx_aligned16(p.rowvec)) return false;      // 16-byte epilogue loads
+    if (p.geglu && p.rowvec) return false;
+    if (p.a_mode == 1) {
+        const int ctot = p.C1 + p.C2;
+        if (ctot % BK != 0 || p.C1 % BK != 0) return false;      // a slab must not straddle a tap or a source
+        if (p.H >= 32768 || p.W >= 32768) return false;          // packed (h0, w0)
+    }
+    return p.M < (1L << 30) && p.K < (1L << 30);
+}
+
+int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
+    const long cols = p.geglu ? 2 * p.N : p.N;
+    p.tiles_n = (int)(cols / 320);
+    p.tiles_total = (int)(((p.M + bm - 1) / bm) * p.tiles_n);
+    // option "pp_sched" (env VSX_PP_SCHED) selects the piece schedule (row of SCHEDS) among the compiled variants
+    const long opt = gemm_option("pp_sched");
+    const bool bpack = opt >= 16 && opt < 32;               // + 16: the caller passes a piece-major (packed) B operand
+    const int variant = (opt & 15) < NSCHED ? (int)(opt & 15) : 0;
+    const bool conv = p.a_mode == 1;
+    if (bpack) {
+        if (p.K % BK != 0 || p.ldb != p.K)
+            return vsx_fail(VSX_E_UNSUPPORTED, "gemm_pp: a packed B operand needs K %% 64 == 0 and ldb == K");
+#define VSX_PP_PACKED(S)                                                                                          \
+    if (variant == S) {                                                                                           \
+        if (bm == 256) return conv ? launch_one<2, true, S, true>(p, stream) : launch_one<2, false, S, true>(p, stream); \
+        return conv ? launch_one<1, true, S, true>(p, stream) : launch_one<1, false, S, true>(p, stream);         \
+    }
+        VSX_PP_PACKED(0)
+        VSX_PP_PACKED(3)
+        VSX_PP_PACKED(4)
+#undef VSX_PP_PACKED
+        return vsx_fail(VSX_E_UNSUPPORTED, "gemm_pp: packed B is compiled for schedules 0, 3 and 4");
+    }
+#define VSX_PP_CASE(S)                                                                                  \
+    case S:                                                                                             \
+        if (bm == 256) return conv ? launch_one<2, true, S>(p, stream) : launch_one<2, false, S>(p, stream); \
+        return conv ? launch_one<1, true, S>(p, stream) : launch_one<1, false, S>(p, stream)
+    switch (variant) {
+        VSX_PP_CASE(1);
+        VSX_PP_CASE(2);
+        VSX_PP_CASE(3);
+        VSX_PP_CASE(4);
+        VSX_PP_CASE(5);
+        VSX_PP_CASE(6);
+        default:
+            break;
+    }
+#undef VSX_PP_CASE
+    if (bm == 256) return conv ? launch_one<2, true, 0>(p, stream) : launch_one<2, false, 0>(p, stream);
+    return conv ? launch_one<1, true, 0>(p, stream) : launch_one<1, false, 0>(p, stream);
+}
+
+}  // namespace vsxg
