@@ -1,5 +1,5 @@
 #!/bin/bash
-# Comprehensive gpurun call: gate, A/B, benches, rocprof kernel trace (eager + graphs), PMC passes, full GPU suite.
+# The gpurun call the round-2 profiles were taken with (profiles/README.md): gate, A/B, benches, rocprof kernel trace (eager + graphs), PMC passes, full GPU suite.
 TAG=${1:-r02d}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
