@@ -150,3 +150,40 @@ def test_site_reshard_exchange(world):
         assert at_err < 1e-5
         # one all-to-all moves (world-1)/world of the LOCAL activation: fp16, B x T/world frames x HW/world sites x C
         assert moved == (world - 1) * B * (T // world) * (HW // world) * C * 2
+
+
+def _simulate_alltoall(sends, nouter, ninner, block, send_strides, recv_strides, out_numel):
+    """vsx_alltoall_f16's contract (csrc/experimental/comm.cpp) for all ranks in one process: block (o, i) for peer p
+    leaves rank r at p*ss[0] + o*ss[1] + i*ss[2] and lands on rank p at r*rs[0] + o*rs[1] + i*rs[2]."""
+    world = len(sends)
+    outs = [torch.full((out_numel,), float('nan')) for _ in range(world)]
+    for r in range(world):
+        for p in range(world):
+            for o in range(nouter):
+                for i in range(ninner):
+                    so = p * send_strides[0] + o * send_strides[1] + i * send_strides[2]
+                    do = r * recv_strides[0] + o * recv_strides[1] + i * recv_strides[2]
+                    outs[p][do:do + block] = sends[r][so:so + block]
+    return outs
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_strided_alltoall_layouts_of_the_site_reshard(world):
+    """The stride triples FrameShard hands to the C-ABI all-to-all (no pack / unpack copies) against the layouts the
+    torch.distributed path produces: frames -> sites and back."""
+    torch.manual_seed(1)
+    B, T, HW, C = 2, 2 * world, 3 * world, 5
+    f, hl = T // world, HW // world
+    blk = hl * C
+    x = torch.randn(B, T, HW, C)
+    local = [x[:, r * f:(r + 1) * f].reshape(-1) for r in range(world)]                       # [b, f, (p, hl), c]
+    from videoswap_amd.distributed import FrameShard
+    to_sites = FrameShard.reshard_strides(world, f, blk)        # what to_sites / to_frames hand to the C ABI
+    to_frames = to_sites[::-1]
+    sites = _simulate_alltoall(local, B, f, blk, *to_sites, out_numel=B * T * hl * C)
+    for r in range(world):
+        want = x[:, :, r * hl:(r + 1) * hl].reshape(-1)                                       # all frames, my sites
+        assert torch.equal(sites[r], want), r
+    back = _simulate_alltoall(sites, B, f, blk, *to_frames, out_numel=B * f * HW * C)
+    for r in range(world):
+        assert torch.equal(back[r], local[r]), r

@@ -174,3 +174,30 @@ def test_frame_sharded_unet_matches_full_clip_oracle(exchange):
           f'unsharded half-clip {uncoupled:.3e}')
     assert err < 4e-3
     assert uncoupled > 3 * err
+
+
+@pytest.mark.skipif(os.environ.get('VSX_LIB_VARIANT') != 'next',
+                    reason='vsx_alltoall_f16 is exported by the development library only (VSX_LIB_VARIANT=next)')
+def test_alltoall_entry_point_single_rank():
+    """vsx_alltoall_f16 with a one-rank communicator: the strided self-block copy must reproduce the re-shard layouts
+    (the multi-rank stride arithmetic is checked on CPU: tests/test_distributed.py::test_strided_alltoall_layouts...)."""
+    import ctypes
+    from videoswap_amd import _lib, ops
+    from videoswap_amd.distributed import FrameShard
+    lib = _lib.load()
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(lib.vsx_comm_unique_id(uid), 'vsx_comm_unique_id')
+    _lib.check(lib.vsx_comm_init(0, 1, uid), 'vsx_comm_init')
+    try:
+        b, f, hl, c = 2, 3, 8, 64
+        blk = hl * c
+        y = torch.randn(b * f * hl, c, device='cuda', dtype=torch.float16)
+        out = torch.zeros_like(y)
+        send_st, recv_st = FrameShard.reshard_strides(1, f, blk)
+        arr = ctypes.c_int64 * 3
+        _lib.check(lib.vsx_alltoall_f16(ops._p(y), ops._p(out), b, f, blk, arr(*send_st), arr(*recv_st), ops._stream()),
+                   'vsx_alltoall_f16')
+        torch.cuda.synchronize()
+        assert torch.equal(out, y)
+    finally:
+        _lib.check(lib.vsx_comm_destroy(), 'vsx_comm_destroy')

@@ -22,6 +22,8 @@ for s in 0 3 4 5 6; do
   ( VSX_LIB_VARIANT=next VSX_TEST_PP_SCHED=$s timeout 200 python -m pytest tests/test_kernels_gpu.py -q -k persistent -rf ) > $O/${TAG}_next_pp_s$s.log 2>&1
   echo "next lib, pp_sched $s: $(tail -n 1 $O/${TAG}_next_pp_s$s.log | cut -c1-120)"
 done
+( VSX_LIB_VARIANT=next timeout 100 python -m pytest tests/test_frame_shard_gpu.py -q -k alltoall -rf ) > $O/${TAG}_next_alltoall.log 2>&1
+echo "next lib, alltoall: $(tail -n 1 $O/${TAG}_next_alltoall.log | cut -c1-120)"
 VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 2 --rounds 4 --scheds 0,3,4,5,6 > $O/${TAG}_next_sched_b2.txt 2>&1
 tail -n 3 $O/${TAG}_next_sched_b2.txt | cut -c1-250
 VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 2 --rounds 4 --scheds 0,4,16,20 --bpack > $O/${TAG}_next_bpack_b2.txt 2>&1

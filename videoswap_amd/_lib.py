@@ -91,6 +91,12 @@ PROTOTYPES = {
     'vsx_prof_collect': (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
 }
 
+# entry points that only the development variant exports so far (typed when present)
+OPTIONAL_PROTOTYPES = {
+    'vsx_alltoall_f16': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64),
+                                 c_void_p]),
+}
+
 _lib = None
 
 
@@ -108,6 +114,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
+    for name, (restype, argtypes) in OPTIONAL_PROTOTYPES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = restype
+            fn.argtypes = argtypes
     ver = lib.vsx_abi_version()
     if ver != VSX_ABI_VERSION:
         raise VsxError(f'libvsx ABI version {ver} != expected {VSX_ABI_VERSION}; rebuild the extension')

@@ -183,17 +183,43 @@ class FrameShard:
                              f"{self.world} ranks (use exchange='kv' for this latent size)")
         return hw // self.world
 
+    def _alltoall_strided(self, src, dst, b, block, send_strides, recv_strides):
+        """RCCL path of both re-shards through the C ABI (vsx_alltoall_f16: grouped send / recv straight from / into the
+        strided layouts, no pack / unpack passes).  Only the development library exports it so far."""
+        import ctypes
+        from . import _lib, ops
+        arr = ctypes.c_int64 * 3
+        _lib.check(self.comm.lib.vsx_alltoall_f16(ops._p(src), ops._p(dst), b, self.local_frames, block,
+                                                  arr(*send_strides), arr(*recv_strides), ops._stream()),
+                   'vsx_alltoall_f16')
+
+    @staticmethod
+    def reshard_strides(world, local_frames, block):
+        """(send, recv) stride triples (peer, batch item, frame; elements) of the frames -> sites all-to-all between the
+        layouts [b, f, P, hw/P, C] and [b, P, f, hw/P, C] (`block` = hw/P * C); sites -> frames swaps the two."""
+        f, p = local_frames, world
+        return (block, f * p * block, p * block), (f * block, p * f * block, block)
+
+    def _has_c_alltoall(self):
+        return self.comm is not None and getattr(self.comm.lib, 'vsx_alltoall_f16', None) is not None
+
     def to_sites(self, y, b, hw):
         """y [b*f_local*hw, C] (this rank's frames, all sites) -> [b*F_total*hw_local, C] (all frames, this rank's
         sites), rows in (b, frame, site) order with the frames in rank order = global order.  One all-to-all."""
         c = y.shape[-1]
         f, p = self.local_frames, self.world
         hl = self.sites_per_rank(hw)
-        # destination-major send blocks [p][b, f, hl, c]: one strided copy (the only extra pass on this side)
+        blk = hl * c
+        self.bytes_gathered += (p - 1) * b * f * blk * y.element_size()
+        if self._has_c_alltoall():
+            out = torch.empty(b * p * f * hl, c, dtype=y.dtype, device=y.device)          # [b, p(source), f, hl, c]
+            send_st, recv_st = self.reshard_strides(p, f, blk)
+            self._alltoall_strided(y, out, b, blk, send_st, recv_st)
+            return out
+        # destination-major send blocks [p][b, f, hl, c]: one strided copy on each side of the collective
         send = y.view(b, f, p, hl, c).permute(2, 0, 1, 3, 4).contiguous()
         recv = torch.empty_like(send)                                    # [source rank s][b, f(s), hl, c]
         _all_to_all(recv.view(p, -1), send.view(p, -1), self.group)
-        self.bytes_gathered += (p - 1) * b * f * hl * c * y.element_size()
         # frames of source s are global frames [s*f, (s+1)*f): (s, b, f) -> (b, s, f)
         return recv.permute(1, 0, 2, 3, 4).reshape(b * p * f * hl, c)
 
@@ -202,10 +228,16 @@ class FrameShard:
         c = ys.shape[-1]
         f, p = self.local_frames, self.world
         hl = self.sites_per_rank(hw)
+        blk = hl * c
+        self.bytes_gathered += (p - 1) * b * f * blk * ys.element_size()
+        if self._has_c_alltoall():
+            out = torch.empty(b * f * hw, c, dtype=ys.dtype, device=ys.device)            # [b, f, p(source), hl, c]
+            recv_st, send_st = self.reshard_strides(p, f, blk)
+            self._alltoall_strided(ys, out, b, blk, send_st, recv_st)
+            return out
         send = ys.view(b, p, f, hl, c).permute(1, 0, 2, 3, 4).contiguous()   # block d = frames owned by rank d
         recv = torch.empty_like(send)                                        # [source s][b, f, hl(s), c]
         _all_to_all(recv.view(p, -1), send.view(p, -1), self.group)
-        self.bytes_gathered += (p - 1) * b * f * hl * c * ys.element_size()
         # sites of source s are [s*hl, (s+1)*hl): (s, b, f, hl) -> (b, f, s, hl)
         return recv.permute(1, 2, 0, 3, 4).reshape(b * f * hw, c)
 
