@@ -1,0 +1,821 @@
+// DEVELOPMENT VARIANT of ../attention.hip (library variant "next"; NOT part of the measured libvsx.so).  Difference:
+// the flash kernel's workgroup can have 8 waves = 256 query rows sharing one K / V^T tile stream (environment
+// VSX_FLASH_WAVES=8, for nq >= 2048).  Why: at N = 4096, d = 40 a 128-query workgroup pulls 10 KiB of K | V^T per 64-key
+// tile for 1.3 MFLOP — the same bytes per FLOP as the GEMM's 256x320 tile — and four such workgroups per CU need
+// ~40 KiB per ~1000 cycles, i.e. the ~35 B/clk a CU gets from L2 as 128-byte row segments: the measured 850-1200 cycles
+// per tile (profiles/r01_probes/attention_timing.txt) match the DMA time, not MFMA (448) + VALU (440).  256 queries per
+// tile stream halve the bytes per FLOP.  Per-wave arithmetic and key order are unchanged: bit-identical results.
+//
+// K5/K6 — fused attention for gfx950: O = softmax(Q K^T * scale) V with online softmax on
+// v_mfma_f32_32x32x16_f16, scores never leave the register file.
+//
+// Work split: workgroup = 4 wave64 = 128 query rows of one (image, head); each wave owns 32
+// query rows and walks the keys in tiles of 64.  Both products are computed TRANSPOSED so that
+// every per-query quantity (running max m, running sum l, rescale factor) is lane-local:
+//
+//   S^T[key, q] = K[key, :] . Q[q, :]      A = K tile (LDS), B = Q fragments (registers)
+//   O^T[c,   q] = V^T[c, key] . P^T[key,q] A = V^T tile (LDS), B = P (registers, straight from S^T)
+//
+// In the 32x32 MFMA C/D layout a lane holds column q = lane&31 and 16 of the 32 rows, so the
+// lane pair (q, q+32) holds a full score column: row max / row sum are 15 local ops plus one
+// cross-lane exchange, and the exponentiated scores are already in B-operand position for the
+// second product (the k-slot -> key assignment of P is matched when V^T fragments are read).
+// V arrives pre-transposed per image (vsx_gemm_f16 c_mode 1 writes V^T while projecting), which
+// keeps every LDS fragment read a contiguous 8/16-byte access.
+//
+// LDS: K tile [64][DK*16+8] halfs (row = 2*DK+1 16-byte slots, odd => conflict-free b128 reads); LDS row r holds key
+//      r with bits 2,3 swapped, which makes a lane's 8 scores per MFMA step 8 consecutive keys;
+//      V^T tile [DT*32][72] halfs (144-byte rows = 9 slots, odd => conflict-free b128 reads).
+#include "common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+struct AttnParams {
+    const half_t* Q;
+    const half_t* K;
+    const half_t* VT;
+    half_t* O;
+    int nq, nk, heads;
+    long ldq, ldk, ldvt, ldo;
+    long q_bs, k_bs, vt_bs, o_bs;
+    int kv_div;
+    float scale_log2e;
+};
+
+// -DVSX_GEMM_TIMING (tools/gemm_timing.py): per-wave cycle totals of the key-loop segments, long[block][wave][6]
+#ifdef VSX_GEMM_TIMING
+__device__ long* g_attn_dbg = nullptr;
+#define ASTAMP(i) do { const long t_now = (long)clock64(); t_seg[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+
+constexpr int KV_TILE = 64;
+constexpr int VSTR = 72;          // V^T LDS row: 64 keys + one 16-byte dummy slot (odd slot count)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void flash_attn_kernel(const AttnParams p) {
+    constexpr int NT = 64 * NW;         // threads: NW waves of 32 query rows each
+    constexpr int DK = (D + 15) / 16;   // k-steps of the QK^T product
+    constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T
+    constexpr int KSTR = DK * 16 + 8;   // K LDS row (halfs): 2*DK real/zero slots + one dummy slot (odd slot count)
+    constexpr bool HAS_SPARE = (DT * 32 > D);   // a padding row of the O^T tile can carry the softmax denominator
+    constexpr int KSPR = KSTR / 8, VSPR = VSTR / 8;              // 16-byte slots per LDS row
+    constexpr int K_UNITS = KV_TILE * KSPR, V_UNITS = D * VSPR;  // 16-byte units per tile (V: rows < D only)
+    constexpr int NKI = (K_UNITS + NT - 1) / NT, NVI = (V_UNITS + NT - 1) / NT;   // LDS-DMA instructions per wave
+    constexpr int K_BYTES = KV_TILE * KSTR * 2;
+    constexpr int V_BYTES = DT * 32 * VSTR * 2;
+    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int OOB_OFF = (int)0x80000000;
+
+    // two-slot LDS ring filled by LDS-DMA (`buffer_load_dwordx4 ... lds`): tile j+1 streams in while tile j is
+    // consumed; per-lane offsets are loop-invariant, the key position advances in the scalar offset, out-of-range
+    // rows / pad slots read as zero through the buffer descriptor
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    // XCD-aware order (1-D grid): workgroup id b lands on XCD b % 8; give every XCD a contiguous range of
+    // (image, head, query-tile) so the query tiles that share one head's K / V^T stream them from the same L2
+    int wg = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7;
+        const int xcd = wg & 7, local = wg >> 3;
+        wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + local;
+    }
+    const int qtiles = (p.nq + 32 * NW - 1) / (32 * NW);
+    const int qt = wg % qtiles;
+    const int h = (wg / qtiles) % p.heads;
+    const long b = wg / (qtiles * p.heads);
+    const long kvb = b / p.kv_div;
+
+    const int q = qt * (32 * NW) + wave * 32 + l31;
+    const bool qok = q < p.nq;
+
+    // Q fragments: B operand of S^T = K Q^T; lane (q, hi) holds Q[q, t*16 + hi*8 .. +7]
+    h8 qf[DK];
+    {
+        const half_t* qrow = p.Q + b * p.q_bs + (long)(qok ? q : 0) * p.ldq + h * D;
+#pragma unroll
+        for (int t = 0; t < DK; ++t) {
+            const int d0 = t * 16 + hi * 8;
+            qf[t] = (qok && d0 < D) ? as_h8(ld16(qrow + d0)) : as_h8(make_uint4(0, 0, 0, 0));
+        }
+    }
+
+    const half_t* Kb = p.K + kvb * p.k_bs + h * D;
+    const half_t* Vb = p.VT + kvb * p.vt_bs + (long)h * D * p.ldvt;
+    const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(Kb), 0, (int)((((long)p.nk - 1) * p.ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(Vb), 0, (int)((long)D * p.ldvt * 2), 0x00020000);
+    int vk[NKI], vv[NVI];
+#pragma unroll
+    for (int i = 0; i < NKI; ++i) {
+        const int u = (wave * NKI + i) * 64 + lane;
+        const int row = u / KSPR, slot = u - row * KSPR;
+        // LDS row r of the K tile holds key krow(r) = r with bits 2 and 3 swapped: in the 32x32 C/D layout a lane then
+        // owns 8 CONSECUTIVE keys per (tile, half) instead of two groups of 4, so the matching V^T fragment of the
+        // second product is one ds_read_b128
+        const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
+        vk[i] = (u < K_UNITS && slot * 8 < D) ? (int)(((long)key * p.ldk + slot * 8) * 2) : OOB_OFF;
+    }
+#pragma unroll
+    for (int i = 0; i < NVI; ++i) {
+        const int u = (wave * NVI + i) * 64 + lane;
+        const int row = u / VSPR, slot = u - row * VSPR;
+        vv[i] = (u < V_UNITS && slot < 8) ? (int)(((long)row * p.ldvt + slot * 8) * 2) : OOB_OFF;
+    }
+    // rows >= D of the V^T tiles are never written by the DMA: zero them once, and put the ones row in place
+    for (int i = tid; i < 2 * (DT * 32 - D) * VSTR; i += NT) {
+        const int st = i / ((DT * 32 - D) * VSTR), r = i - st * ((DT * 32 - D) * VSTR);
+        const int row = D + r / VSTR, col = r - (r / VSTR) * VSTR;
+        half_t* sv = reinterpret_cast<half_t*>(smem + st * STAGE + K_BYTES);
+        // the ones row is the LAST row of the tile: the tail lanes of the final V^T DMA instruction write zeros into
+        // the (up to 7) rows right after row D-1, so row D itself is not safe
+        sv[row * VSTR + col] = (HAS_SPARE && row == DT * 32 - 1 && col < KV_TILE) ? (half_t)1.f : (half_t)0.f;
+    }
+
+    auto issue = [&](int j0, int stage) {
+        unsigned char* sb = smem + stage * STAGE;
+        const int soffK = (int)((long)j0 * p.ldk * 2);
+        const int soffV = j0 * 2;
+        // the descriptor's range check does not cover the scalar offset: in the last, partial tile the rows / key
+        // slots past the end are switched off per lane (once per workgroup)
+        const bool partial = j0 + KV_TILE > p.nk;
+#pragma unroll
+        for (int i = 0; i < NKI; ++i)
+            if ((wave * NKI + i) * 64 < K_UNITS) {     // wave-uniform
+                int v = vk[i];
+                if (partial) {
+                    const int row = ((wave * NKI + i) * 64 + lane) / KSPR;
+                    if (j0 + ((row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1)) >= p.nk) v = OOB_OFF;
+                }
+                // lanes past the end of the tile are switched off (EXEC): a DMA lane always writes its 16 bytes,
+                // zeros included, and would clobber the neighbouring LDS region
+                if ((wave * NKI + i) * 64 + lane < K_UNITS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, (lds_ptr_t)(sb + (wave * NKI + i) * 1024), 16, v,
+                                                             soffK, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < NVI; ++i)
+            if ((wave * NVI + i) * 64 < V_UNITS) {
+                int v = vv[i];
+                if (partial) {
+                    const int u = (wave * NVI + i) * 64 + lane;
+                    if (j0 + (u - (u / VSPR) * VSPR) * 8 >= p.ldvt) v = OOB_OFF;
+                }
+                if ((wave * NVI + i) * 64 + lane < V_UNITS)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, (lds_ptr_t)(sb + K_BYTES + (wave * NVI + i) * 1024),
+                                                             16, v, soffV, 0, 0);
+            }
+    };
+
+    f16v o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_i = -INFINITY;
+    float l_i = 0.f;
+
+    issue(0, 0);
+    int stage = 0;
+#ifdef VSX_GEMM_TIMING
+    long t_seg[6] = {0, 0, 0, 0, 0, 0}, t_last = (long)clock64();
+#endif
+    for (int j0 = 0; j0 < p.nk; j0 += KV_TILE, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ASTAMP(0);
+        __syncthreads();   // tile j0 is in LDS for every wave; the other slot is no longer being read
+        ASTAMP(1);
+        if (j0 + KV_TILE < p.nk) issue(j0 + KV_TILE, stage ^ 1);
+        ASTAMP(2);
+        const half_t* sK = reinterpret_cast<const half_t*>(smem + stage * STAGE);
+        const half_t* sV = reinterpret_cast<const half_t*>(smem + stage * STAGE + K_BYTES);
+
+        // ---- S^T = K Q^T : two 32-key row tiles ----
+        f16v s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const half_t* krow = sK + (kt * 32 + l31) * KSTR + hi * 8;
+            const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < DK; ++t) {
+                const h8 kf = *reinterpret_cast<const h8*>(krow + t * 16);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t], t == 0 ? zero : s[kt], 0, 0, 0);
+            }
+        }
+        ASTAMP(3);
+        // ---- online softmax (lane-local per query column); VALU budget: max3, fma, exp2, cvt per score ----
+        if (j0 + KV_TILE > p.nk) {   // only the last, partial key tile needs masking (wave-uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // C/D row (r&3) + 8*(r>>2) + 4*hi of the tile holds key (r&3) + 4*((r>>2)&1) + 8*hi + 16*(r>>3)
+                    const int key = j0 + kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
+                    if (key >= p.nk) s[kt][r] = -INFINITY;
+                }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2e;      // scale > 0: max commutes with the scaling
+        if (!__all(mx <= m_i)) {     // running max grows: rescale O (and the denominator row inside it)
+            const float m_new = fmaxf(m_i, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+            m_i = m_new;
+            if (!HAS_SPARE) l_i *= alpha;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
+        const float neg_m = -m_i;
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], p.scale_log2e, neg_m));
+                s[kt][r] = e;
+                if (!HAS_SPARE) rs += e;
+            }
+        if (!HAS_SPARE) {
+            rs += __shfl_xor(rs, 32, 64);
+            l_i += rs;
+        }
+
+        ASTAMP(4);
+        // ---- O^T += V^T P^T ----
+        // B operand k-slot jj of (kt, s2) on lane hi carries key kt*32 + 16*s2 + 8*hi + jj (K rows are permuted)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                h8 pf;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)s[kt][8 * s2 + jj];
+                const int c0 = kt * 32 + 16 * s2 + 8 * hi;
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const h8 vf = *reinterpret_cast<const h8*>(sV + (t * 32 + l31) * VSTR + c0);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
+                }
+            }
+        }
+        ASTAMP(5);
+    }
+
+#ifdef VSX_GEMM_TIMING
+    if (lane == 0 && g_attn_dbg) {
+        long* o_dbg = g_attn_dbg + ((long)blockIdx.x * NW + wave) * 6;
+        for (int k = 0; k < 6; ++k) o_dbg[k] = t_seg[k];
+    }
+#endif
+    if (HAS_SPARE) {
+        // the denominator sits in the last row (31) of the last O^T tile: register 15 of the lanes with hi == 1;
+        // broadcast it to the lane pair
+        constexpr int reg = 15;
+        constexpr int owner_hi = 1;
+        const float mine = o[DT - 1][reg];
+        const float other = __shfl_xor(mine, 32, 64);
+        l_i = (hi == owner_hi) ? mine : other;
+    }
+
+    // ---- normalise and store: lane (q, hi) holds O[q, t*32 + 8*g + 4*hi + 0..3] ----
+    if (qok) {
+        const float inv = 1.0f / l_i;
+        half_t* orow = p.O + b * p.o_bs + (long)q * p.ldo + h * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = t * 32 + 8 * g + 4 * hi;
+                if (c < D) {
+                    h4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g + e] * inv);
+                    *reinterpret_cast<h4*>(orow + c) = pk;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch_attn(const AttnParams& p, long nb, hipStream_t stream) {
+    // VSX_FLASH_WAVES=8: 256-query workgroups for the long self-attentions (read per call: an A/B run toggles it)
+    const char* e = getenv("VSX_FLASH_WAVES");
+    if (e && atoi(e) == 8 && p.nq >= 2048 && D <= 80) {
+        dim3 grid((unsigned)(((p.nq + 255) / 256) * (long)p.heads * nb));
+        hipLaunchKernelGGL((flash_attn_kernel<D, 8>), grid, dim3(512), 0, stream, p);
+        return vsx_check_launch("vsx_attention_f16");
+    }
+    dim3 grid((unsigned)(((p.nq + 127) / 128) * (long)p.heads * nb));
+    hipLaunchKernelGGL((flash_attn_kernel<D, 4>), grid, dim3(256), 0, stream, p);
+    return vsx_check_launch("vsx_attention_f16");
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 — temporal self-attention across frames at each spatial site.  One wave per
+// (batch, site, head): Q/K/V rows of the site ([f, d], d contiguous in HBM) are staged in LDS,
+// scores and softmax in fp32.  FLOPs are negligible (0.1 % of the UNet); the kernel is bound by
+// the strided HBM reads, which adjacent heads of a site turn into full 128-byte lines in L2.
+// ---------------------------------------------------------------------------------------------
+struct TempParams {
+    const half_t* Q;
+    const half_t* K;
+    const half_t* V;
+    half_t* O;
+    int fq, fk, hw, heads, d;
+    long ldq, ldkv, ldo;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const TempParams p) {
+    // 4 waves per workgroup, one (site, head) problem per wave (heads are split over blockIdx.y * 4 + wave); each wave
+    // has its own LDS slice, the workgroup barriers only keep the four waves in step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int d = p.d, fq = p.fq, fk = p.fk;
+    const int wave = threadIdx.x >> 6;
+    const size_t slice = (((size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float)) + 15) & ~(size_t)15;
+    unsigned char* base = smem_raw + wave * slice;
+    half_t* sQ = reinterpret_cast<half_t*>(base);        // [fq][d]
+    half_t* sK = sQ + fq * d;                            // [fk][d]
+    half_t* sV = sK + fk * d;                            // [fk][d]
+    float* sS = reinterpret_cast<float*>(sV + fk * d);   // [fq][fk]
+
+    const int lane = threadIdx.x & 63;
+    const long site = blockIdx.x;
+    const int h = min((int)blockIdx.y * 4 + wave, p.heads - 1);   // surplus waves redo the last head (same values)
+    const long b = blockIdx.z;
+    const int dv = d >> 3;
+
+    // Stage Q, K, V: all of a batch's global loads are issued before the first LDS store (the loop used to wait for
+    // every 16-byte load before issuing the next one: one or two requests in flight per wave, 2 TB/s)
+    constexpr int UB = 4;
+    for (int i0 = lane; i0 < fq * dv; i0 += 64 * UB) {
+        uint4 r[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < fq * dv) {
+                const int f = i / dv, c = (i - f * dv) * 8;
+                r[u] = ld16(p.Q + ((b * fq + f) * p.hw + site) * p.ldq + h * d + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < fq * dv) {
+                const int f = i / dv, c = (i - f * dv) * 8;
+                st16(sQ + f * d + c, r[u]);
+            }
+        }
+    }
+    for (int i0 = lane; i0 < fk * dv; i0 += 64 * UB) {
+        uint4 rk[UB], rv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < fk * dv) {
+                const int f = i / dv, c = (i - f * dv) * 8;
+                const long row = (b * fk + f) * p.hw + site;
+                rk[u] = ld16(p.K + row * p.ldkv + h * d + c);
+                rv[u] = ld16(p.V + row * p.ldkv + h * d + c);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < fk * dv) {
+                const int f = i / dv, c = (i - f * dv) * 8;
+                st16(sK + f * d + c, rk[u]);
+                st16(sV + f * d + c, rv[u]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < fq * fk; i += 64) {
+        const int f = i / fk, g = i - f * fk;
+        float acc = 0.f;
+        for (int c = 0; c < d; c += 8) {
+            const h8 a = *reinterpret_cast<const h8*>(sQ + f * d + c);
+            const h8 k = *reinterpret_cast<const h8*>(sK + g * d + c);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {     // v_dot2_f32_f16: two fp16 products accumulated in fp32
+                const h2 a2 = {a[e], a[e + 1]}, k2 = {k[e], k[e + 1]};
+                acc = __builtin_amdgcn_fdot2(a2, k2, acc, false);
+            }
+        }
+        sS[i] = acc * p.scale;
+    }
+    __syncthreads();
+    for (int f = lane; f < fq; f += 64) {
+        float mx = -INFINITY;
+        for (int g = 0; g < fk; ++g) mx = fmaxf(mx, sS[f * fk + g]);
+        float sum = 0.f;
+        for (int g = 0; g < fk; ++g) {
+            const float e = __expf(sS[f * fk + g] - mx);
+            sS[f * fk + g] = e;
+            sum += e;
+        }
+        const float inv = 1.0f / sum;
+        for (int g = 0; g < fk; ++g) sS[f * fk + g] *= inv;
+    }
+    __syncthreads();
+    for (int i = lane; i < fq * dv; i += 64) {
+        const int f = i / dv, c = (i - f * dv) * 8;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int g = 0; g < fk; ++g) {
+            const float pr = sS[f * fk + g];
+            const h8 v = *reinterpret_cast<const h8*>(sV + g * d + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pr * (float)v[e];
+        }
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+        st16(p.O + ((b * fq + f) * p.hw + site) * p.ldo + h * d + c, as_u4(o));
+    }
+}
+
+
+// K8 on the matrix cores.  A (site, head) problem is only fq x fk x d (16 x 16 x 40): G = 32 / max(fq, fk) problems —
+// consecutive heads of one site — are packed along BOTH dimensions of a 32x32 tile, S^T[(g,key), (g',query)], and the
+// off-diagonal blocks (g != g') are masked to zero probability, which makes P block-diagonal so that one
+// O^T[c, (g',query)] = V^T[c, (g,key)] . P^T product serves all packed problems.  Operands of the first product are
+// loaded straight from HBM into MFMA registers (a lane's 16 bytes = 8 consecutive channels of one (frame, head) row;
+// MFMA row r carries packed key swap23(r), so the exponentiated scores are already a B operand, as in the flash
+// kernel); V goes through a wave-private LDS tile, written transposed ([channel][key]) and read back as b128.
+// One wave per G heads, four waves (independent, no barriers) per workgroup.  The first version did these products
+// with per-lane dot products over LDS copies of Q, K, V and was VALU/LDS-bound at 2 TB/s.
+template <int D>
+__global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const TempParams p) {
+    constexpr int DK = (D + 15) / 16;      // k-steps of S^T = K Q^T
+    constexpr int DT = (D + 31) / 32;      // 32-row tiles of O^T
+    constexpr int DV = D / 8;              // 16-byte chunks per (frame, head) row
+    constexpr int VSTR = 40;               // V^T LDS row: 32 keys + 8 pad halfs (5 slots, odd)
+    constexpr int NVL = (32 * DV + 63) / 64;
+    __shared__ __attribute__((aligned(16))) half_t smem[4][DT * 32 * VSTR];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int fq = p.fq, fk = p.fk;
+    const int G = 32 / max(fq, fk);
+    const long site = blockIdx.x;
+    const long b = blockIdx.z;
+    const int head0 = ((int)blockIdx.y * 4 + wave) * G;
+    if (head0 >= p.heads) return;          // waves are independent: no barrier below
+    half_t* sVT = smem[wave];
+
+    // ---- V: coalesced 16-byte loads, transposed scatter into LDS (zeros for padding keys / heads) ----
+    {
+        uint4 raw[NVL];
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int u = lane + 64 * i;
+            const int key = u / DV, ch = u - key * DV;
+            const int g = key / fk, f = key - g * fk;
+            const bool ok = u < 32 * DV && g < G && head0 + g < p.heads;
+            raw[i] = ok ? ld16(p.V + ((b * fk + f) * p.hw + site) * p.ldkv + (long)(head0 + g) * D + ch * 8)
+                        : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int u = lane + 64 * i;
+            if (u < 32 * DV) {
+                const int key = u / DV, ch = u - key * DV;
+                const h8 v = as_h8(raw[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sVT[(ch * 8 + e) * VSTR + key] = v[e];
+            }
+        }
+    }
+
+    // ---- S^T = K Q^T: MFMA row r <- packed key swap23(r), column <- packed query ----
+    const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    const int kg = krow / fk, kf_ = krow - kg * fk;
+    const bool kok = kg < G && head0 + kg < p.heads;
+    const int qg = l31 / fq, qf_ = l31 - qg * fq;
+    const bool qok = qg < G && head0 + qg < p.heads;
+    const half_t* kptr = p.K + ((b * fk + kf_) * p.hw + site) * p.ldkv + (long)(head0 + kg) * D + hi * 8;
+    const half_t* qptr = p.Q + ((b * fq + qf_) * p.hw + site) * p.ldq + (long)(head0 + qg) * D + hi * 8;
+    h8 ka[DK], qb[DK];
+#pragma unroll
+    for (int t = 0; t < DK; ++t) {
+        const bool in = t * 16 + hi * 8 < D;
+        ka[t] = (kok && in) ? as_h8(ld16(kptr + t * 16)) : as_h8(make_uint4(0, 0, 0, 0));
+        qb[t] = (qok && in) ? as_h8(ld16(qptr + t * 16)) : as_h8(make_uint4(0, 0, 0, 0));
+    }
+    const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16v sc = zero;
+#pragma unroll
+    for (int t = 0; t < DK; ++t) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[t], qb[t], t == 0 ? zero : sc, 0, 0, 0);
+
+    // ---- softmax over the keys of this column's own problem (register r holds packed key (r&3)+4*((r>>2)&1)+8*hi+16*(r>>3)) ----
+    const int lo = qg * fk, up = lo + fk;
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
+        const bool v = qok && key >= lo && key < up;
+        sc[r] = v ? sc[r] * sl2 : -INFINITY;
+        mx = fmaxf(mx, sc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;         // padding column: every probability is exp2(-inf) = 0
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sc[r] = __builtin_amdgcn_exp2f(sc[r] - mx);
+        sum += sc[r];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+    // ---- O^T = V^T P^T (P block-diagonal, unnormalised, fp16; normalised in fp32 afterwards) ----
+    f16v o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = zero;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        h8 pf;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)sc[8 * s2 + jj];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const h8 vf = *reinterpret_cast<const h8*>(sVT + (t * 32 + l31) * VSTR + 16 * s2 + 8 * hi);
+            o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
+        }
+    }
+    if (qok) {
+        half_t* orow = p.O + ((b * fq + qf_) * p.hw + site) * p.ldo + (long)(head0 + qg) * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = t * 32 + 8 * g4 + 4 * hi;
+                if (c < D) {
+                    h4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g4 + e] * inv);
+                    *reinterpret_cast<h4*>(orow + c) = pk;
+                }
+            }
+    }
+}
+
+// Long-clip form of the matrix-core kernel (frame-sharded mode): fq local query frames (<= 32) against
+// fk gathered key frames (<= 128).  G = 32 / fq heads are packed along the QUERY dimension only; for every packed head
+// g and every block of 32 keys one S^T tile [32 keys of head g] x [(g', query)] is computed and a column keeps it iff
+// g == g'; the softmax then runs over the column's own 32*NKB score registers, and the second product walks the same
+// (g, key block) pairs with P zeroed for the other heads' columns.  V^T tiles go through the wave-private LDS tile one
+// (head, key block) at a time.
+template <int D>
+__global__ __launch_bounds__(256) void temporal_attn_mfma_long_kernel(const TempParams p) {
+    constexpr int DK = (D + 15) / 16;
+    constexpr int DT = (D + 31) / 32;
+    constexpr int DV = D / 8;
+    constexpr int VSTR = 40;
+    constexpr int NVL = (32 * DV + 63) / 64;
+    constexpr int NKB = 4;                 // key blocks of 32 held in registers: fk <= 128
+    __shared__ __attribute__((aligned(16))) half_t smem[4][DT * 32 * VSTR];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int fq = p.fq, fk = p.fk;
+    const int G = 32 / fq;
+    const int nkb = (fk + 31) >> 5;
+    const long site = blockIdx.x;
+    const long b = blockIdx.z;
+    const int head0 = ((int)blockIdx.y * 4 + wave) * G;
+    if (head0 >= p.heads) return;          // waves are independent: no barrier below
+    half_t* sVT = smem[wave];
+
+    const int qg = l31 / fq, qf_ = l31 - qg * fq;
+    const bool qok = qg < G && head0 + qg < p.heads;
+    const half_t* qptr = p.Q + ((b * fq + qf_) * p.hw + site) * p.ldq + (long)(head0 + qg) * D + hi * 8;
+    h8 qb[DK];
+#pragma unroll
+    for (int t = 0; t < DK; ++t)
+        qb[t] = (qok && t * 16 + hi * 8 < D) ? as_h8(ld16(qptr + t * 16)) : as_h8(make_uint4(0, 0, 0, 0));
+
+    const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f16v sc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) sc[kb] = zero;
+    const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);      // MFMA row r carries key swap23(r)
+    for (int g = 0; g < G; ++g) {
+        if (head0 + g >= p.heads) break;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nkb) continue;
+            const int key = kb * 32 + krow;
+            const half_t* kptr = p.K + ((b * fk + key) * p.hw + site) * p.ldkv + (long)(head0 + g) * D + hi * 8;
+            f16v tile = zero;
+#pragma unroll
+            for (int t = 0; t < DK; ++t) {
+                const h8 ka = (key < fk && t * 16 + hi * 8 < D) ? as_h8(ld16(kptr + t * 16)) : as_h8(make_uint4(0, 0, 0, 0));
+                tile = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qb[t], tile, 0, 0, 0);
+            }
+            if (g == qg) sc[kb] = tile;
+        }
+    }
+
+    // ---- softmax over the fk keys of this column (register r of block kb holds key 32 kb + (r&3) + 4((r>>2)&1) + 8 hi + 16 (r>>3)) ----
+    const float sl2 = p.scale * 1.44269504088896340736f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
+            const bool v = qok && kb < nkb && key < fk;
+            sc[kb][r] = v ? sc[kb][r] * sl2 : -INFINITY;
+            mx = fmaxf(mx, sc[kb][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[kb][r] = __builtin_amdgcn_exp2f(sc[kb][r] - mx);
+            sum += sc[kb][r];
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+    // ---- O^T = sum over (head g, key block) of V^T[c, keys] . P^T[keys, (g', query)], P = 0 where g' != g ----
+    f16v o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = zero;
+    for (int g = 0; g < G; ++g) {
+        if (head0 + g >= p.heads) break;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nkb) continue;
+            uint4 raw[NVL];
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const int u = lane + 64 * i;
+                const int kk = u / DV, ch = u - kk * DV;
+                const int key = kb * 32 + kk;
+                raw[i] = (u < 32 * DV && key < fk)
+                             ? ld16(p.V + ((b * fk + key) * p.hw + site) * p.ldkv + (long)(head0 + g) * D + ch * 8)
+                             : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const int u = lane + 64 * i;
+                if (u < 32 * DV) {
+                    const int kk = u / DV, ch = u - kk * DV;
+                    const h8 v = as_h8(raw[i]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sVT[(ch * 8 + e) * VSTR + kk] = v[e];
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                h8 pf;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[jj] = g == qg ? (half_t)sc[kb][8 * s2 + jj] : (half_t)0.f;
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const h8 vf = *reinterpret_cast<const h8*>(sVT + (t * 32 + l31) * VSTR + 16 * s2 + 8 * hi);
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (qok) {
+        half_t* orow = p.O + ((b * fq + qf_) * p.hw + site) * p.ldo + (long)(head0 + qg) * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = t * 32 + 8 * g4 + 4 * hi;
+                if (c < D) {
+                    h4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g4 + e] * inv);
+                    *reinterpret_cast<h4*>(orow + c) = pk;
+                }
+            }
+    }
+}
+
+template <int D>
+int launch_temporal_mfma_long(const TempParams& p, long B, hipStream_t stream) {
+    const int G = 32 / p.fq;
+    const int groups = (p.heads + G - 1) / G;
+    dim3 grid((unsigned)p.hw, (unsigned)((groups + 3) / 4), (unsigned)B);
+    hipLaunchKernelGGL((temporal_attn_mfma_long_kernel<D>), grid, dim3(256), 0, stream, p);
+    return vsx_check_launch("vsx_temporal_attention_f16");
+}
+
+template <int D>
+int launch_temporal_mfma(const TempParams& p, long B, hipStream_t stream) {
+    const int G = 32 / (p.fq > p.fk ? p.fq : p.fk);
+    const int groups = (p.heads + G - 1) / G;
+    dim3 grid((unsigned)p.hw, (unsigned)((groups + 3) / 4), (unsigned)B);
+    hipLaunchKernelGGL((temporal_attn_mfma_kernel<D>), grid, dim3(256), 0, stream, p);
+    return vsx_check_launch("vsx_temporal_attention_f16");
+}
+
+}  // namespace
+
+#ifdef VSX_GEMM_TIMING
+extern "C" int vsx_attn_debug_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+extern "C" int vsx_attention_f16(const void* Q, const void* K, const void* VT, void* O, int64_t nb, int64_t heads,
+                                 int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk, int64_t ldvt,
+                                 int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t vt_bs, int64_t o_bs,
+                                 int64_t kv_div, float scale, vsx_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    VSX_REQUIRE(Q && K && VT && O, VSX_E_BADSHAPE, "attention: null tensor");
+    if (nb == 0 || nq == 0) return VSX_OK;
+    VSX_REQUIRE(nb > 0 && heads > 0 && nq > 0 && nk > 0 && kv_div > 0, VSX_E_BADSHAPE, "attention: bad sizes");
+    VSX_REQUIRE(nb <= 65535 && heads <= 65535, VSX_E_BADSHAPE, "attention: nb/heads exceed grid limits");
+    VSX_REQUIRE(vsx_aligned16(Q) && vsx_aligned16(K) && vsx_aligned16(VT) && vsx_aligned16(O), VSX_E_BADSHAPE,
+                "attention: tensors must be 16-byte aligned");
+    VSX_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, VSX_E_BADSHAPE,
+                "attention: row strides must be multiples of 8 (ldo: 4)");
+    VSX_REQUIRE(q_bs % 8 == 0 && k_bs % 8 == 0 && vt_bs % 8 == 0 && o_bs % 4 == 0, VSX_E_BADSHAPE,
+                "attention: batch strides must be multiples of 8");
+    VSX_REQUIRE(ldvt >= ((nk + 7) / 8) * 8, VSX_E_BADSHAPE, "attention: ldvt (%ld) < round_up(nk=%ld, 8)", (long)ldvt,
+                (long)nk);
+    AttnParams p;
+    p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.VT = (const half_t*)VT; p.O = (half_t*)O;
+    p.nq = (int)nq; p.nk = (int)nk; p.heads = (int)heads;
+    p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo;
+    p.q_bs = q_bs; p.k_bs = k_bs; p.vt_bs = vt_bs; p.o_bs = o_bs;
+    p.kv_div = (int)kv_div;
+    p.scale_log2e = scale * 1.44269504088896340736f;
+    switch (d) {
+        case 8: return launch_attn<8>(p, nb, stream);
+        case 16: return launch_attn<16>(p, nb, stream);
+        case 32: return launch_attn<32>(p, nb, stream);
+        case 40: return launch_attn<40>(p, nb, stream);
+        case 64: return launch_attn<64>(p, nb, stream);
+        case 80: return launch_attn<80>(p, nb, stream);
+        case 128: return launch_attn<128>(p, nb, stream);
+        case 160: return launch_attn<160>(p, nb, stream);
+        default: return vsx_fail(VSX_E_UNSUPPORTED, "attention: head dim %ld not in {8,16,32,40,64,80,128,160}", (long)d);
+    }
+}
+
+extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const void* V, void* O, int64_t B, int64_t fq,
+                                          int64_t fk, int64_t hw, int64_t heads, int64_t d, int64_t ldq, int64_t ldkv,
+                                          int64_t ldo, float scale, vsx_stream_t stream) {
+    VSX_REQUIRE(Q && K && V && O, VSX_E_BADSHAPE, "temporal_attention: null tensor");
+    if (B == 0 || hw == 0) return VSX_OK;
+    VSX_REQUIRE(B > 0 && fq > 0 && fk > 0 && hw > 0 && heads > 0 && d > 0, VSX_E_BADSHAPE, "temporal_attention: bad sizes");
+    VSX_REQUIRE(d % 8 == 0 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0, VSX_E_BADSHAPE,
+                "temporal_attention: d and row strides must be multiples of 8");
+    VSX_REQUIRE(vsx_aligned16(Q) && vsx_aligned16(K) && vsx_aligned16(V) && vsx_aligned16(O), VSX_E_BADSHAPE,
+                "temporal_attention: tensors must be 16-byte aligned");
+    VSX_REQUIRE(B <= 65535 && heads <= 65535, VSX_E_BADSHAPE, "temporal_attention: grid limits");
+    TempParams p;
+    p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
+    p.fq = (int)fq; p.fk = (int)fk; p.hw = (int)hw; p.heads = (int)heads; p.d = (int)d;
+    p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.scale = scale;
+    if (fq <= 32 && fk <= 32) {            // matrix-core kernel for the UNet's head dims
+        if (d == 40) return launch_temporal_mfma<40>(p, B, (hipStream_t)stream);
+        if (d == 80) return launch_temporal_mfma<80>(p, B, (hipStream_t)stream);
+        if (d == 160) return launch_temporal_mfma<160>(p, B, (hipStream_t)stream);
+    } else if (fq <= 32 && fk <= 128) {    // long-clip mode: local query frames against the gathered key frames
+        if (d == 40) return launch_temporal_mfma_long<40>(p, B, (hipStream_t)stream);
+        if (d == 80) return launch_temporal_mfma_long<80>(p, B, (hipStream_t)stream);
+        if (d == 160) return launch_temporal_mfma_long<160>(p, B, (hipStream_t)stream);
+    }
+    const size_t slice = (((size_t)(fq + 2 * fk) * d * sizeof(half_t) + (size_t)fq * fk * sizeof(float)) + 15) & ~(size_t)15;
+    const size_t smem = 4 * slice;
+    VSX_REQUIRE(smem <= 160 * 1024, VSX_E_UNSUPPORTED, "temporal_attention: %zu bytes of LDS needed (> 160 KiB)", smem);
+    static size_t smem_attr = 64 * 1024;
+    if (smem > smem_attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&temporal_attn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "temporal_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        smem_attr = 160 * 1024;
+    }
+    dim3 grid((unsigned)hw, (unsigned)((heads + 3) / 4), (unsigned)B);
+    hipLaunchKernelGGL(temporal_attn_kernel, grid, dim3(256), smem, (hipStream_t)stream, p);
+    return vsx_check_launch("vsx_temporal_attention_f16");
+}
