@@ -30,7 +30,3 @@ VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 2 --rounds 4 --
 tail -n 3 $O/${TAG}_next_bpack_b2.txt | cut -c1-250
 VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 1 --rounds 4 --scheds 0,3,4,5,6 > $O/${TAG}_next_sched_b1.txt 2>&1
 tail -n 2 $O/${TAG}_next_sched_b1.txt | cut -c1-250
-VSX_LIB_VARIANT=next timeout 200 python tools/attn_ab.py --batch 2 > $O/${TAG}_next_attn_ab.txt 2>&1
-tail -n 5 $O/${TAG}_next_attn_ab.txt | cut -c1-200
-( VSX_LIB_VARIANT=next VSX_FLASH_WAVES=8 timeout 200 python -m pytest tests/test_kernels_gpu.py -q -k "attention" -rf ) > $O/${TAG}_next_attn_tests.log 2>&1
-echo "next lib, 8-wave flash attention tests: $(tail -n 1 $O/${TAG}_next_attn_tests.log | cut -c1-120)"

@@ -23,8 +23,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIB = os.path.join(LIBDIR, 'libvsx.so')
 # variant name -> {source file of SOURCES: replacement, relative to csrc/}
-VARIANTS = {'next': {'gemm_pp.hip': 'experimental/gemm_pp.hip', 'comm.cpp': 'experimental/comm.cpp',
-                     'attention.hip': 'experimental/attention.hip'}}
+VARIANTS = {'next': {'gemm_pp.hip': 'experimental/gemm_pp.hip', 'comm.cpp': 'experimental/comm.cpp'}}
 SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
