@@ -101,7 +101,11 @@ class FrameShard:
     vsx_allgather_f32) on a side stream: the K|V all-gather of a temporal attention overlaps with its q projection.
     `backend='torch'` uses torch.distributed (`all_gather_into_tensor`; gloo in the CPU tests and the single-GPU
     emulation).  Either way each exchange is ONE collective per batch item into a preallocated buffer laid out as the
-    attention kernel reads it ([B, F_total, hw, 2C]: K = columns [0, C), V = [C, 2C))."""
+    attention kernel reads it ([B, F_total, hw, 2C]: K = columns [0, C), V = [C, 2C)).
+
+    `exchange='kv'` (default, the form that has run on hardware) gathers the temporal K|V; `exchange='sites'` re-shards
+    the activation frames <-> sites around every motion module instead (module docstring): `to_sites` / `to_frames`,
+    one all-to-all each (torch.distributed, or the library's vsx_alltoall_f16 once it exports it)."""
 
     def __init__(self, total_frames, group=None, backend=None, exchange='kv'):
         if exchange not in ('kv', 'sites'):
