@@ -74,11 +74,13 @@ def _heads(t, heads):
     return t.float().view(b, n, heads, c // heads).permute(0, 2, 1, 3)        # [b, h, n, d]
 
 
-def attention_scores(q, k, heads, scale, kv_div=1, causal=False):
+def attention_scores(q, k, heads, scale, kv_div=1, causal=False, softmax=True):
     qh = _heads(q, heads)
     kh = _heads(k, heads).repeat_interleave(kv_div, dim=0)
     s = (qh @ kh.transpose(-1, -2)) * scale
     s = s.to(H).float()                                   # the kernel stores the scaled scores in fp16 first
+    if not softmax:
+        return s.to(H)
     if causal:
         nq, nk = s.shape[-2:]
         s = s.masked_fill(torch.ones(nq, nk, dtype=torch.bool).triu(1), float('-inf'))
@@ -221,6 +223,94 @@ def adapter_scatter(tracks, selected, feat, h, w, rate, out_scale=1.0):
     return out
 
 
+# ---- gradient path (videoswap_amd/autograd.py builds the backward passes from these) ----
+def _gelu_parts(g):
+    cdf = 0.5 * (1.0 + torch.erf(g * 0.7071067811865476))
+    pdf = torch.exp(-0.5 * g * g) * 0.3989422804014327
+    return cdf, pdf
+
+
+def geglu_fwd(y2):
+    h, g = y2.float().chunk(2, dim=-1)
+    return (h * F.gelu(g)).to(H)
+
+
+def geglu_bwd(dout, y2):
+    h, g = y2.float().chunk(2, dim=-1)
+    cdf, pdf = _gelu_parts(g)
+    d = dout.float()
+    return torch.cat([d * g * cdf, d * h * (cdf + g * pdf)], dim=-1).to(H)
+
+
+def silu_bwd(dy, x):
+    xf = x.float()
+    sg = torch.sigmoid(xf)
+    return (dy.float() * (sg + xf * sg * (1.0 - sg))).to(H)
+
+
+def group_norm_bwd(dy, x, gamma, beta, groups, eps, nimg, silu=False, x2=None):
+    xin = (x if x2 is None else torch.cat([x, x2], dim=-1)).float().requires_grad_(True)
+    C = xin.shape[-1]
+    with torch.enable_grad():
+        xs = xin.reshape(nimg, -1, groups, C // groups)
+        mean = xs.mean((1, 3), keepdim=True)
+        var = xs.var((1, 3), unbiased=False, keepdim=True)
+        y = ((xs - mean) * (var + eps).rsqrt()).reshape(nimg, -1, C) * gamma.float() + beta.float()
+        if silu:
+            y = F.silu(y)
+        (g,) = torch.autograd.grad(y, xin, dy.float().reshape(y.shape))
+    g = g.to(H)
+    if x2 is None:
+        return g, None
+    c1 = x.shape[-1]
+    return g[..., :c1].contiguous(), g[..., c1:].contiguous()
+
+
+def layer_norm_bwd(dy, x, gamma, eps=1e-5):
+    xf = x.float().requires_grad_(True)
+    with torch.enable_grad():
+        y = F.layer_norm(xf, (x.shape[-1],), gamma.float(), None, eps)
+        (g,) = torch.autograd.grad(y, xf, dy.float())
+    return g.to(H)
+
+
+def softmax_bwd(probs, dprobs, scale):
+    p, dp = probs.float(), dprobs.float()
+    ds = scale * p * (dp - (dp * p).sum(-1, keepdim=True))
+    dprobs.copy_(ds.to(H))
+    return dprobs
+
+
+def sum_pool2x2(x):
+    n, h2, w2, c = x.shape
+    return x.float().view(n, h2 // 2, 2, w2 // 2, 2, c).sum((2, 4)).to(H)
+
+
+def adapter_gather(tracks, selected, dmap, rate, out_scale=1.0):
+    Fr, P = tracks.shape[:2]
+    _, h, w, C = dmap.shape
+    out = torch.zeros(P, C, dtype=torch.float32)
+    r16 = lambda v: torch.tensor(v, dtype=torch.float32).to(H).float().item()     # noqa: E731
+    for f in range(Fr):
+        for pt in range(P):
+            if not int(selected[pt]):
+                continue
+            px, py = float(tracks[f, pt, 0]), float(tracks[f, pt, 1])
+            if px < 0 or py < 0:
+                continue
+            x, y = r16(r16(px) / rate), r16(r16(py) / rate)
+            x1, y1 = int(x), int(y)
+            x2, y2 = x1 + 1, y1 + 1
+            xf, yf = r16(x - x1), r16(y - y1)
+            x1, x2 = max(min(x1, w - 1), 0), max(min(x2, w - 1), 0)
+            y1, y2 = max(min(y1, h - 1), 0), max(min(y2, h - 1), 0)
+            xm, ym = r16(1.0 - xf), r16(1.0 - yf)
+            wgt = [r16(xm * ym), r16(xf * ym), r16(xm * yf), r16(xf * yf)]
+            for (xx, yy), wg in zip(((x1, y1), (x2, y1), (x1, y2), (x2, y2)), wgt):
+                out[pt] += wg * dmap[f, yy, xx].float()
+    return (out * out_scale).to(H)
+
+
 def gemm(desc):
     raise RuntimeError('host emulation: raw vsx_gemm_f16 descriptors are not emulated (call the typed ops)')
 
@@ -235,18 +325,20 @@ def prof_pause(paused):
 
 _NAMES = ['linear', 'linear_vt', 'conv2d', 'attention_scores', 'head_scores', 'attention_pv', 'attention',
           'temporal_attention', 'group_norm', 'layer_norm', 'silu', 'quick_gelu', 'axpy', 'pack_latents',
-          'unpack_latents', 'cfg_ddim_step', 'masked_blend', 'adapter_scatter', 'gemm', 'set_option', 'prof_pause']
+          'unpack_latents', 'cfg_ddim_step', 'masked_blend', 'adapter_scatter', 'gemm', 'set_option', 'prof_pause',
+          'geglu_fwd', 'geglu_bwd', 'silu_bwd', 'group_norm_bwd', 'layer_norm_bwd', 'softmax_bwd', 'sum_pool2x2',
+          'adapter_gather']
 
 
 @contextlib.contextmanager
 def installed():
-    """Swap the entry points of videoswap_amd.ops for the functions above (and back)."""
+    """Swap the kernel table of videoswap_amd.ops (`ops._raw`) for the functions above (and back)."""
     from videoswap_amd import ops
-    saved = {n: getattr(ops, n) for n in _NAMES}
+    saved = dict(ops._raw)
     try:
         for n in _NAMES:
-            setattr(ops, n, globals()[n])
+            ops._raw[n] = globals()[n]
         yield ops
     finally:
-        for n, fn in saved.items():
-            setattr(ops, n, fn)
+        ops._raw.clear()
+        ops._raw.update(saved)

@@ -93,6 +93,17 @@ PROTOTYPES = {
 
 # entry points that only the development variant exports so far (typed when present)
 OPTIONAL_PROTOTYPES = {
+    # gradient path of the adapter training step (csrc/experimental/train.hip)
+    'vsx_geglu_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'vsx_geglu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'vsx_silu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'vsx_groupnorm_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                  c_void_p, c_float, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'vsx_layernorm_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_void_p]),
+    'vsx_softmax_bwd': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    'vsx_sum_pool2x2': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    'vsx_adapter_gather': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_void_p]),
     'vsx_alltoall_f16': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64),
                                  c_void_p]),
 }

@@ -186,7 +186,7 @@ def conv2d(x, weight, bias=None, *, x2=None, stride=1, upsample=False, rowvec=No
     return out
 
 
-def attention_scores(q, k, heads, scale, kv_div=1, causal=False):
+def attention_scores(q, k, heads, scale, kv_div=1, causal=False, softmax=True):
     """probs = softmax(scale * q k^T) materialised (the Prompt-to-Prompt hook path).
 
     q [nb, nq, C], k [nkvb, nk, C] -> probs [nb, heads, nq, nk] (a view of a buffer whose rows are padded to a
@@ -220,6 +220,8 @@ def attention_scores(q, k, heads, scale, kv_div=1, causal=False):
             d.c_bs0 = heads * nq * ld; d.c_bs1 = nq * ld
             d.alpha = float(scale)
             gemm(d)
+    if not softmax:                  # the raw scaled products (gradient path: dP = dO V^T has the same shape)
+        return buf[..., :nk]
     if causal:
         check(_lib.load().vsx_softmax_rows_causal(_p(buf), nb * heads * nq, nk, ld, nq, _stream()),
               'vsx_softmax_rows_causal')
@@ -495,3 +497,153 @@ def prof_collect():
     fl = ctypes.c_double(0)
     check(_lib.load().vsx_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl)), 'vsx_prof_collect')
     return n.value, ms.value, fl.value
+
+
+# --------------------------------------------------------------------------------------------
+# kernel functions of the gradient path (adapter training step).  Their kernels live in the development
+# library (csrc/experimental/train.hip, VSX_LIB_VARIANT=next) until they have been verified on hardware.
+# --------------------------------------------------------------------------------------------
+def _train_fn(name):
+    fn = getattr(_lib.load(), name, None)
+    if fn is None:
+        raise _lib.VsxError(f'{name}: the training kernels are part of the development library only '
+                            f'(python -m videoswap_amd.build --variant next; VSX_LIB_VARIANT=next)')
+    return fn
+
+
+def geglu_fwd(y2):
+    """y2 [.., 2N] = (h | g) pre-activations -> h * gelu_erf(g) [.., N] (the GEMM's GEGLU epilogue as its own pass: the
+    gradient needs the pre-activations)."""
+    _chk(y2, 'y2')
+    n = y2.shape[-1] // 2
+    out = torch.empty(*y2.shape[:-1], n, dtype=_F16, device=y2.device)
+    check(_train_fn('vsx_geglu_fwd')(_p(y2), _p(out), y2.numel() // (2 * n), n, _stream()), 'vsx_geglu_fwd')
+    return out
+
+
+def geglu_bwd(dout, y2):
+    """-> d y2 [.., 2N]: dh = dout * gelu(g), dg = dout * h * gelu'(g)."""
+    _chk(dout, 'dout'); _chk(y2, 'y2')
+    n = y2.shape[-1] // 2
+    dy2 = torch.empty_like(y2)
+    check(_train_fn('vsx_geglu_bwd')(_p(dout), _p(y2), _p(dy2), y2.numel() // (2 * n), n, _stream()), 'vsx_geglu_bwd')
+    return dy2
+
+
+def silu_bwd(dy, x):
+    _chk(dy, 'dy'); _chk(x, 'x')
+    dx = torch.empty_like(x)
+    check(_train_fn('vsx_silu_bwd')(_p(dy), _p(x), _p(dx), x.numel(), _stream()), 'vsx_silu_bwd')
+    return dx
+
+
+def group_norm_bwd(dy, x, gamma, beta, groups, eps, nimg, silu=False, x2=None):
+    """Data gradient of `group_norm` (same arguments; dy [.., C1+C2]) -> (dx [.., C1], dx2 [.., C2] or None)."""
+    _chk(dy, 'dy'); _chk(x, 'x'); _chk(x2, 'x2'); _chk(gamma, 'gamma'); _chk(beta, 'beta')
+    C1 = x.shape[-1]
+    C2 = x2.shape[-1] if x2 is not None else 0
+    rows = x.numel() // C1 // nimg
+    dx = torch.empty_like(x)
+    dx2 = torch.empty_like(x2) if x2 is not None else None
+    ws = torch.empty(nimg, groups, 4, dtype=torch.float32, device=x.device)
+    check(_train_fn('vsx_groupnorm_bwd')(_p(dy), _p(x), _p(x2), nimg, rows, C1, C2, groups, _p(gamma), _p(beta),
+                                         float(eps), 1 if silu else 0, _p(ws), _p(dx), _p(dx2), _stream()),
+          'vsx_groupnorm_bwd')
+    return dx, dx2
+
+
+def layer_norm_bwd(dy, x, gamma, eps=1e-5):
+    """Data gradient of `layer_norm` (the positional encoding is added after the normalisation: it does not enter)."""
+    _chk(dy, 'dy'); _chk(x, 'x'); _chk(gamma, 'gamma')
+    C = x.shape[-1]
+    dx = torch.empty_like(x)
+    check(_train_fn('vsx_layernorm_bwd')(_p(dy), _p(x), _p(gamma), float(eps), _p(dx), x.numel() // C, C, _stream()),
+          'vsx_layernorm_bwd')
+    return dx
+
+
+def softmax_bwd(probs, dprobs, scale):
+    """dS = scale * P o (dP - rowsum(dP o P)), written over dP.  Both are views of row-padded buffers as
+    `attention_scores` returns them ([nb, heads, nq, nk], row stride ld)."""
+    nb, heads, nq, nk = probs.shape
+    ld = probs.stride(2)
+    if dprobs.shape != probs.shape or dprobs.stride() != probs.stride() or probs.stride(3) != 1:
+        raise _lib.VsxError('softmax_bwd: probs and dprobs must share shape and (padded-row) strides')
+    _chk_view(probs, 'probs'); _chk_view(dprobs, 'dprobs')
+    check(_train_fn('vsx_softmax_bwd')(_p(probs), _p(dprobs), nb * heads * nq, nk, ld, float(scale), _stream()),
+          'vsx_softmax_bwd')
+    return dprobs
+
+
+def sum_pool2x2(x):
+    """[n, 2h, 2w, c] -> [n, h, w, c]: the data gradient of the nearest-2x upsampling folded into a conv's loader."""
+    _chk(x, 'x')
+    n, h2, w2, c = x.shape
+    y = torch.empty(n, h2 // 2, w2 // 2, c, dtype=_F16, device=x.device)
+    check(_train_fn('vsx_sum_pool2x2')(_p(x), _p(y), n, h2 // 2, w2 // 2, c, _stream()), 'vsx_sum_pool2x2')
+    return y
+
+
+def adapter_gather(tracks, selected, dmap, rate, out_scale=1.0):
+    """Gradient of `adapter_scatter` with respect to feat: dfeat[p, :] = out_scale * sum over frames and the 4 bilinear
+    corners of weight * dmap[f, y, x, :] (same fp16 sub-pixel positions and weights as the forward)."""
+    _chk(tracks, 'tracks', torch.float32); _chk(selected, 'selected', torch.int32); _chk(dmap, 'dmap')
+    F, P = tracks.shape[:2]
+    _, h, w, C = dmap.shape
+    dfeat = torch.zeros(P, C, dtype=_F16, device=dmap.device)
+    check(_train_fn('vsx_adapter_gather')(_p(tracks), _p(selected), _p(dmap), _p(dfeat), F, P, C, h, w, float(rate),
+                                          float(out_scale), _stream()), 'vsx_adapter_gather')
+    return dfeat
+
+
+# --------------------------------------------------------------------------------------------
+# kernel table and gradient dispatch
+# --------------------------------------------------------------------------------------------
+# Every op above is a "kernel function" (it launches HIP kernels and nothing else).  The names the rest of the package
+# calls are thin wrappers that (1) look the kernel function up in `_raw` at call time — one table a test harness can
+# swap as a whole — and (2) when autograd is recording and an ACTIVATION argument requires grad (only the adapter
+# training step, trainer_videoswap.py:33-97: the UNet's weights are frozen), route the call through the matching
+# torch.autograd.Function of videoswap_amd/autograd.py, whose backward is again built from kernel functions.
+_raw = {}
+
+# op name -> positions / keywords of the activation arguments whose requires_grad switches the gradient path on
+_ACTIVATIONS = {
+    'linear': ((0,), ('residual',)), 'linear_vt': ((0,), ()), 'conv2d': ((0,), ('x2', 'residual')),
+    'attention': ((0, 1, 2), ()), 'temporal_attention': ((0, 1, 2), ()), 'attention_scores': ((0, 1), ()),
+    'attention_pv': ((0, 1), ()), 'head_scores': ((0, 1), ()), 'group_norm': ((0,), ('x2',)), 'layer_norm': ((0,), ()),
+    'silu': ((0,), ()), 'quick_gelu': ((0,), ()), 'axpy': ((0, 1), ()), 'pack_latents': ((0,), ()),
+    'unpack_latents': ((0,), ()), 'cfg_ddim_step': ((0, 1, 2), ()), 'masked_blend': ((0, 1), ()),
+    'adapter_scatter': ((2,), ()),
+}
+_PLAIN = ('gemm', 'set_option', 'prof_pause', 'prof_enable', 'prof_collect', 'geglu_fwd', 'geglu_bwd', 'silu_bwd',
+          'group_norm_bwd', 'layer_norm_bwd', 'softmax_bwd', 'sum_pool2x2', 'adapter_gather')
+
+
+def _publish(name):
+    _raw[name] = globals()[name]
+    pos, kws = _ACTIVATIONS.get(name, ((), ()))
+
+    def op(*args, **kwargs):
+        if pos and torch.is_grad_enabled():
+            for i in pos:
+                if i < len(args) and torch.is_tensor(args[i]) and args[i].requires_grad:
+                    break
+            else:
+                for k in kws:
+                    t = kwargs.get(k)
+                    if t is not None and t.requires_grad:
+                        break
+                else:
+                    return _raw[name](*args, **kwargs)
+            from . import autograd
+            return autograd.dispatch(name, *args, **kwargs)
+        return _raw[name](*args, **kwargs)
+
+    op.__name__ = name
+    op.__doc__ = _raw[name].__doc__
+    globals()[name] = op
+
+
+for _name in tuple(_ACTIVATIONS) + _PLAIN:
+    _publish(_name)
+del _name
