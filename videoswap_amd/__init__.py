@@ -18,5 +18,5 @@ def build_model(name):
 
 def build_pipeline(name):
     """videoswap/pipelines/__init__.py:24-32"""
-    from . import pipeline  # noqa: F401
+    from . import pipeline, trainer  # noqa: F401  (pipelines/__init__.py:12-21: pipeline_* and trainer_* modules)
     return PIPELINE_REGISTRY.get(name)

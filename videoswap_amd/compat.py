@@ -208,3 +208,42 @@ class DDIMInverseScheduler(_DDIMBase):
         initial = 1.0 if self.config.set_alpha_to_one else float(self.alphas_cumprod[0])
         a_t = float(self.alphas_cumprod[t]) if t >= 0 else initial
         return a_t, float(self.alphas_cumprod[t + self._ratio()])
+
+
+class DDPMScheduler:
+    """What the training step uses of diffusers' DDPMScheduler (train.py:157-160; trainer_videoswap.py:57,82-90): the
+    noise schedule, `add_noise` (the forward diffusion q(x_t | x_0)) and `get_velocity`."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule='linear',
+                 prediction_type='epsilon', **ignored):
+        self.config = FrozenDict(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                 beta_schedule=beta_schedule, prediction_type=prediction_type)
+        if beta_schedule == 'scaled_linear':
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == 'linear':
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise NotImplementedError(beta_schedule)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        return cls(**{**dict(config), **kwargs})
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_path, subfolder=None, **kwargs):
+        from .formats import scheduler_config_from_pretrained
+        return cls(**{**scheduler_config_from_pretrained(pretrained_model_path, subfolder), **kwargs})
+
+    def _coefficients(self, like, timesteps):
+        a = self.alphas_cumprod.to(device=like.device, dtype=like.dtype)[timesteps.to(like.device)]
+        shape = (-1,) + (1,) * (like.dim() - 1)
+        return (a ** 0.5).view(shape), ((1 - a) ** 0.5).view(shape)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        sa, s1a = self._coefficients(original_samples, timesteps)
+        return sa * original_samples + s1a * noise
+
+    def get_velocity(self, sample, noise, timesteps):
+        sa, s1a = self._coefficients(sample, timesteps)
+        return sa * noise - s1a * sample
