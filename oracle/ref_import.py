@@ -23,6 +23,8 @@ def available():
 
 def _module(name, **attrs):
     m = types.ModuleType(name)
+    # a real spec: importlib.util.find_spec (transformers probes optional packages with it) rejects `__spec__ = None`
+    m.__spec__ = importlib.util.spec_from_loader(name, loader=None)
     m.__dict__.update(attrs)
     sys.modules[name] = m
     return m

@@ -141,3 +141,57 @@ def test_trainer_step_updates_only_the_adapter_and_handles_overflow(dummy):
     trainer.step(batch)
     assert trainer.skipped_steps == 1 and trainer.loss_scale == 5e29
     assert all(torch.equal(snap[k], v) for k, v in pad.state_dict().items())
+
+
+def _train_options(tmp_path, extra=None):
+    """The reference's training option file = its test option file without `pretrained_adapter_path`
+    (options/train_videoswap/animal/2001_catheadturn_T05_Iter100/...yml; tests/golden/config1_options.json)."""
+    import json
+    from util import GOLDEN
+    with open(os.path.join(GOLDEN, 'config1_options.json')) as f:
+        opt = json.load(f)['options']
+    opt['path'].pop('pretrained_adapter_path')
+    small = [{'type': 'Resize', 'size': 256}, {'type': 'ToTensor'}, {'type': 'Normalize', 'mean': [0.5], 'std': [0.5]}]
+    over = {'datasets.num_frames': 3, 'datasets.video_transform': small, 'datasets.dataset_enlarge_ratio': 4,
+            'train.total_iter': 3, 'logger.print_freq': 1, 'logger.save_checkpoint_freq': 3, 'val.val_freq': 3,
+            'val.editing_config.num_inference_steps': 2, 'val.save_type': 'frame_gif'}
+    over.update(extra or {})
+    for dotted, v in over.items():
+        node = opt
+        parts = dotted.split('.')
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return opt
+
+
+@pytest.mark.parametrize('dummy', [pytest.param(0, marks=NEEDS_BWD)])
+def test_train_flow_from_the_option_file_then_test_with_the_trained_adapter(dummy, tmp_path):
+    """train.py's flow on a synthetic workspace in the real on-disk formats (tiny width): three AdamW steps, the
+    checkpoint lands at <experiments>/<name>/models/models_3/adapter.pth in the format test.py loads — and the test.py
+    flow then runs with it."""
+    from videoswap_amd import runner
+    from videoswap_amd.workspace import write_synthetic_workspace
+    opt = _train_options(tmp_path)
+    write_synthetic_workspace(str(tmp_path), opt, width='tiny', total_frames=9)   # 3 frames at stride 4
+    cwd = os.getcwd()
+    os.environ['VSX_RESULTS_ROOT'] = str(tmp_path / 'experiments')
+    os.chdir(tmp_path)
+    try:
+        res = runner.train(str(tmp_path), copy.deepcopy(opt), None, device=DEV)
+        assert len(res['losses']) == 3 and all(l == l and l < 1e4 for l in res['losses'])
+        assert res['trainer'].skipped_steps == 0
+        ckpt = res['checkpoints'][-1]
+        assert ckpt.endswith(os.path.join('models', 'models_3', 'adapter.pth')) and os.path.isfile(ckpt)
+        sd = torch.load(ckpt, map_location='cpu')
+        from videoswap_amd.adapter import SparsePointAdapter
+        assert set(sd) == set(SparsePointAdapter(channels=[64, 128, 256, 256]).state_dict())
+        # the reference's test.py flow with the adapter just trained
+        topt = copy.deepcopy(opt)
+        topt['path']['pretrained_adapter_path'] = ckpt
+        topt['mixed_precision'] = 'fp16'
+        os.environ['VSX_RESULTS_ROOT'] = str(tmp_path / 'results')
+        edited, _ = runner.test(str(tmp_path), topt, None, device=DEV)
+        assert set(edited) == {'kitten_to_catA', 'kitten_to_dogB', 'kitten_to_dogA'}
+    finally:
+        os.chdir(cwd)

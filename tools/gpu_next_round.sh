@@ -30,3 +30,6 @@ VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 2 --rounds 4 --
 tail -n 3 $O/${TAG}_next_bpack_b2.txt | cut -c1-250
 VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 1 --rounds 4 --scheds 0,3,4,5,6 > $O/${TAG}_next_sched_b1.txt 2>&1
 tail -n 2 $O/${TAG}_next_sched_b1.txt | cut -c1-250
+# ---- gradient path / training step on the development library's backward kernels ----
+( VSX_LIB_VARIANT=next timeout 300 python -m pytest tests/test_autograd.py tests/test_training.py -m gpu -q -s -rf ) > $O/${TAG}_next_training.log 2>&1
+grep -E "loss:|worst cosine|level|passed|failed" $O/${TAG}_next_training.log | cut -c1-200

@@ -87,7 +87,7 @@ class SparsePointAdapter(ModelMixin, ConfigMixin):
         import random
         tracks = point_tracker.squeeze(0) if point_tracker.dim() == 4 else point_tracker
         emb = point_embedding.squeeze(0) if point_embedding.dim() == 3 else point_embedding
-        w, h = size
+        w, h = int(size[0]), int(size[1])            # a DataLoader hands over one-element tensors
         num_frames, num_points = tracks.shape[:2]
         loss_mask = None
         if self.training:

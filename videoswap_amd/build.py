@@ -24,6 +24,8 @@ OBJDIR = os.path.join(LIBDIR, 'obj')
 LIB = os.path.join(LIBDIR, 'libvsx.so')
 # variant name -> {source file of SOURCES: replacement, relative to csrc/}
 VARIANTS = {'next': {'gemm_pp.hip': 'experimental/gemm_pp.hip', 'comm.cpp': 'experimental/comm.cpp'}}
+# variant name -> additional sources (relative to csrc/)
+VARIANT_EXTRA = {'next': ['experimental/train.hip']}
 SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
@@ -49,6 +51,9 @@ def _digest(variant=None):
             h.update(name.encode() + b'\0' + f.read())
     h.update(' '.join(f.replace(ROOT, '<root>') for f in FLAGS).encode())
     if variant:
+        for name in VARIANT_EXTRA.get(variant, []):
+            with open(os.path.join(CSRC, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
         h.update(b'\0variant ' + variant.encode())
     return h.hexdigest()
 
@@ -74,7 +79,7 @@ def built_digest(variant=None):
 def _compile(src, digest, variant=None):
     objdir = OBJDIR if not variant else os.path.join(LIBDIR, f'obj_{variant}')
     os.makedirs(objdir, exist_ok=True)
-    obj = os.path.join(objdir, src + '.o')
+    obj = os.path.join(objdir, src.replace('/', '_') + '.o')
     extra = [f'-DVSX_SOURCE_DIGEST="{digest}"'] if src == 'api.cpp' else []
     path = os.path.join(CSRC, (VARIANTS[variant] if variant else {}).get(src, src))
     cmd = [HIPCC] + FLAGS + extra + ['-c', path, '-o', obj]
@@ -97,8 +102,9 @@ def build(force=False, verbose=True, variant=None):
         return lib
     if not os.path.exists(HIPCC):
         raise RuntimeError(f'{HIPCC} not found: cannot build {os.path.basename(lib)}')
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(lambda src: _compile(src, digest, variant), SOURCES))
+    sources = SOURCES + (VARIANT_EXTRA.get(variant, []) if variant else [])
+    with ThreadPoolExecutor(max_workers=len(sources)) as ex:
+        objs = list(ex.map(lambda src: _compile(src, digest, variant), sources))
     cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + ['-ldl']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

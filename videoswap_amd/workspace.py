@@ -169,7 +169,8 @@ def write_synthetic_workspace(root, opt, width='tiny', seed=1234, total_frames=N
     # ---- adapter, ED-LoRA checkpoints ----
     adapter = SparsePointAdapter(**adapter_cfg)
     synth_weights_(adapter, seed=seed + 3)
-    _save(adapter.state_dict(), at(opt['path']['pretrained_adapter_path']))
+    if opt['path'].get('pretrained_adapter_path'):          # absent in the training option files (train.py builds a fresh one)
+        _save(adapter.state_dict(), at(opt['path']['pretrained_adapter_path']))
     loras = []
     for i, cfg in enumerate(opt['val']['editing_config']['editing_prompts'].values()):
         if not cfg.get('lora_path'):
