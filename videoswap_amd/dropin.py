@@ -17,9 +17,10 @@ SHIMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'shims')
 def install():
     if SHIMS not in sys.path:
         sys.path.insert(0, SHIMS)
-    for name in [m for m in sys.modules if m == 'videoswap' or m.startswith('videoswap.')]:
-        if not getattr(sys.modules[name], '__file__', '').startswith(SHIMS):
-            del sys.modules[name]
+    for name in list(sys.modules):          # anything already imported under the shimmed names must come from the shims
+        if name.split('.')[0] in ('videoswap', 'diffusers', 'omegaconf'):
+            if not (getattr(sys.modules[name], '__file__', None) or '').startswith(SHIMS):
+                del sys.modules[name]
 
 
 def main(argv=None):

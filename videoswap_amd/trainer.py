@@ -87,8 +87,19 @@ class VideoSwapTrainer(VideoSwapPipeline):
         return loss, pred
 
     def backward_and_update(self, loss):
-        """accelerator.backward + optimizer / lr-scheduler step with the dynamic loss scale (see the module docstring).
-        Returns True when the update was applied."""
+        """accelerator.backward + optimizer / lr-scheduler step.  With an `accelerate.Accelerator` handed in (the
+        reference's train.py does) its calls are made verbatim (trainer_videoswap.py:95-101: its GradScaler does the
+        loss scaling); without one, the dynamic loss scale of the module docstring.  Returns True when the update was
+        applied."""
+        acc = self.accelerator
+        if acc is not None:
+            acc.backward(loss)
+            if acc.sync_gradients:
+                acc.clip_grad_norm_(self.unet.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            self.lr_scheduler.step()
+            self.optimizer.zero_grad()
+            return True
         (loss * self.loss_scale).backward()
         params = [p for p in self.adapter.parameters() if p.grad is not None]
         finite = all(bool(torch.isfinite(p.grad).all()) for p in params)

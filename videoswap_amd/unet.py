@@ -676,6 +676,12 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         from .graphs import GraphCache
         self._graphs = GraphCache(eager_every) if enabled else None
 
+    def enable_gradient_checkpointing(self):
+        """train.py:85-87 calls it when the option file says `gradient_checkpointing: true`.  The reference needs it to fit
+        its activations in 24-48 GB; one 288-GB GPU keeps the ~40 GB tape of a 16-frame 512x512 step resident, so nothing
+        is recomputed here."""
+        self.gradient_checkpointing = True
+
     def invalidate_graphs(self):
         self._weights_epoch += 1
 

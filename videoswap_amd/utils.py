@@ -6,6 +6,8 @@ import os
 import shutil
 import time
 
+import torch
+
 
 def get_time_str():
     return time.strftime('%Y%m%d_%H%M%S', time.localtime())
@@ -69,3 +71,50 @@ def save_video_to_dir(edit_video, save_dir, save_suffix, save_type='frame', fps=
                     wr.append_data(np.array(img))
         except ImportError:
             save_images_as_gif(edit_video, os.path.join(save_dir, f'{save_suffix}.mp4.gif'), fps=fps)
+
+
+class MessageLogger:
+    """logger.py:136-195: one line per `print_freq` iterations (iteration, learning rates, elapsed / remaining time,
+    the reduced losses)."""
+
+    def __init__(self, opt, start_iter=1, loss_print='f'):
+        import time
+        self.exp_name = opt['name']
+        self.interval = opt['logger']['print_freq']
+        self.start_iter = start_iter
+        self.max_iters = opt['train']['total_iter']
+        self.start_time = time.time()
+        self.logger = logging.getLogger('videoswap')
+        self.loss_print = loss_print
+
+    def reset_start_time(self):
+        import time
+        self.start_time = time.time()
+
+    def __call__(self, log_vars):
+        import datetime
+        import time
+        current_iter = log_vars.pop('iter')
+        lrs = log_vars.pop('lrs')
+        message = f'[{self.exp_name[:5]}..][Iter:{current_iter:8,d}, lr:(' + ''.join(f'{v:.3e},' for v in lrs) + ')] '
+        total = time.time() - self.start_time
+        per_iter = total / max(current_iter - self.start_iter + 1, 1)
+        eta = str(datetime.timedelta(seconds=int(per_iter * (self.max_iters - current_iter - 1))))
+        message += f'[eta: {eta}] '
+        for k, v in log_vars.items():
+            message += f'{k}: {v:.4e} ' if self.loss_print == 'e' else f'{k}: {v:.4f} '
+        self.logger.info(message)
+
+
+def reduce_loss_dict(accelerator, loss_dict):
+    """logger.py:198-225: average every loss over the processes -> {name: float}."""
+    from collections import OrderedDict
+    with torch.no_grad():
+        keys = list(loss_dict)
+        losses = torch.stack([loss_dict[k].detach().float() for k in keys], 0)
+        world = 1
+        if accelerator is not None:
+            losses = accelerator.reduce(losses)
+            world = accelerator.num_processes
+        losses = losses / world
+        return OrderedDict((k, float(v.mean())) for k, v in zip(keys, losses))
