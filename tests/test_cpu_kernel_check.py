@@ -1,0 +1,31 @@
+"""The backward kernels of the training step (videoswap_amd/csrc/experimental/train.hip) executed FROM THEIR SOURCE on the
+CPU: tools/cpu_check/hip/hip_runtime.h maps the HIP execution model of these simple kernels (a workgroup = OS threads,
+__syncthreads = a barrier, __shfl_xor = an exchange between two wave barriers) onto the host, tools/cpu_check/check_train.cpp
+calls every C-ABI entry point and compares with a double-precision restatement of the formula.  This checks index
+arithmetic and reduction logic without a GPU; the GPU tests (tests/test_autograd.py, VSX_LIB_VARIANT=next) remain the
+parity tests proper."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from util import ROOT
+
+CXX = os.environ.get('CXX_HOST', '/opt/rocm/lib/llvm/bin/clang++')
+
+
+@pytest.mark.skipif(not (os.path.isfile(CXX) or shutil.which('clang++')), reason='needs clang++ (C++20, _Float16)')
+def test_backward_kernels_run_from_source_on_the_cpu(tmp_path):
+    cxx = CXX if os.path.isfile(CXX) else shutil.which('clang++')
+    src = os.path.join(ROOT, 'tools', 'cpu_check')
+    exe = str(tmp_path / 'check_train')
+    cmd = [cxx, '-std=c++20', '-O1', '-pthread', '-I', src, '-I', os.path.join(ROOT, 'include'), '-I',
+           os.path.join(ROOT, 'videoswap_amd', 'csrc'), '-Wno-unused-function', '-o', exe,
+           os.path.join(src, 'check_train.cpp')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count(' ok') == 11
