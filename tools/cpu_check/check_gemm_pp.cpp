@@ -1,0 +1,223 @@
+// Runs the persistent ping-pong GEMM of the development library (videoswap_amd/csrc/experimental/gemm_pp.hip) on the CPU
+// from its real source — every piece schedule (option pp_sched), both tile heights, plain / residual / GEGLU epilogues,
+// the packed-B addressing — and compares with a double-precision GEMM; the schedules must also agree bit for bit with
+// schedule 0.  See hip_gemm.h for what the emulation covers (addressing, LDS layout, MFMA fragment layout, epilogue) and
+// what it cannot (the asynchronous ordering of the LDS-DMA).
+#define CPUHIP_DYNAMIC_LDS_ONLY
+#include "hip/hip_runtime.h"
+#include "hip_gemm.h"
+
+#include <stdarg.h>
+
+#include "common.h"
+
+int vsx_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "\n");
+    return code;
+}
+int vsx_check_launch(const char*) { return 0; }
+
+static long g_sched = 0;
+#include "gemm_common.h"
+namespace vsxg {
+long gemm_option(const char*) { return g_sched; }
+namespace {
+CPUHIP_DEFINE_LDS
+}
+}
+#include "experimental/gemm_pp.hip"
+
+static unsigned rng_state = 777u;
+static float frand() {
+    rng_state = rng_state * 1664525u + 1013904223u;
+    return (float)((rng_state >> 8) & 0xFFFF) / 32768.0f - 1.0f;
+}
+static std::vector<half_t> randh(size_t n, float scale = 1.0f) {
+    std::vector<half_t> v(n);
+    for (auto& x : v) x = (half_t)(frand() * scale);
+    return v;
+}
+static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
+
+struct Case { const char* name; long M, N, K; bool res, geglu; int bm; };
+
+static int n_bad = 0;
+static std::vector<long> g_scheds = {0, 1, 2, 3, 4, 5, 6, 16, 19, 20};
+
+static std::vector<half_t> pack_b(const std::vector<half_t>& w, long rows, long K) {      // [N/8][K/64][8][64]
+    std::vector<half_t> out(w.size());
+    const long nk = K / 64;
+    for (long r = 0; r < rows; ++r)
+        for (long k = 0; k < K; ++k)
+            out[((r / 8) * nk + k / 64) * 512 + (r % 8) * 64 + (k % 64)] = w[r * K + k];
+    return out;
+}
+
+static void run_case(const Case& c) {
+    using namespace vsxg;
+    const long brows = c.geglu ? 2 * c.N : c.N;
+    auto A = randh(c.M * c.K), B = randh(brows * c.K, 1.0f / sqrtf((float)c.K)), bias = randh(brows);
+    auto R = randh(c.M * c.N);
+    if (getenv("CPUHIP_ONES")) {
+        for (long m = 0; m < c.M; ++m) for (long k = 0; k < c.K; ++k) A[m * c.K + k] = (half_t)(k == atoi(getenv("CPUHIP_ONES")) ? 1.f : 0.f);
+        for (long n = 0; n < brows; ++n) for (long k = 0; k < c.K; ++k) B[n * c.K + k] = (half_t)(float)(k);
+        for (auto& b : bias) b = (half_t)0.f;
+    }
+    auto Bp = (c.K % 64 == 0) ? pack_b(B, brows, c.K) : std::vector<half_t>();
+    // reference
+    std::vector<double> want(c.M * c.N);
+    for (long m = 0; m < c.M; ++m)
+        for (long n = 0; n < c.N; ++n) {
+            auto dot = [&](long row) {
+                double s = 0;
+                for (long k = 0; k < c.K; ++k) s += (double)A[m * c.K + k] * (double)B[row * c.K + k];
+                return s + (double)bias[row];
+            };
+            double v = c.geglu ? dot(n) * gelu(dot(c.N + n)) : dot(n);
+            if (c.res) v += (double)R[m * c.N + n];
+            want[m * c.N + n] = v;
+        }
+    std::vector<half_t> first;
+    for (long sched : g_scheds) {
+        if (sched >= 16 && Bp.empty()) continue;
+        std::vector<half_t> C(c.M * c.N, (half_t)-7.f);
+        GemmParams p{};
+        p.A = A.data(); p.B = sched >= 16 ? Bp.data() : B.data(); p.C = C.data(); p.bias = bias.data();
+        p.residual = c.res ? R.data() : nullptr;
+        p.M = c.M; p.N = c.N; p.K = c.K;
+        p.lda = c.K; p.ldb = c.K; p.ldc = c.N; p.ldr = c.N;
+        p.batch1 = 1; p.rows_per_vec = 1; p.geglu = c.geglu; p.alpha = 1.0f;
+        p.vec4 = p.vec8 = 1; p.rvec8 = c.res ? 1 : 0;
+        p.a_bytes = (unsigned)(((c.M - 1) * c.K + c.K) * 2);
+        p.b_bytes = (unsigned)(((brows - 1) * c.K + c.K) * 2);
+        p.splitk = 1;
+        if (!pp_supported(p)) { printf("%s: not eligible\n", c.name); return; }
+        g_sched = sched;
+        cpuhip_oob_reads = 0;
+        const int rc = launch_pp(p, c.bm, nullptr);
+        double num = 0, den = 0;
+        for (size_t i = 0; i < want.size(); ++i) {
+            const double d = (double)C[i] - want[i];
+            num += d * d;
+            den += want[i] * want[i];
+        }
+        const double rel = sqrt(num / den);
+        bool same = true;
+        if (first.empty()) first = C;
+        else same = memcmp(first.data(), C.data(), C.size() * sizeof(half_t)) == 0;
+        if (getenv("CPUHIP_ROW")) {
+            const long m = atol(getenv("CPUHIP_ROW"));
+            for (long n = 0; n < c.N; ++n) printf("%g%s", (double)C[m * c.N + n], (n % 32 == 31) ? "\n" : " ");
+            exit(0);
+        }
+        if (getenv("CPUHIP_DEBUG") && rel > 3e-3) {
+            int shown = 0;
+            for (long m = 0; m < c.M && shown < 24; ++m)
+                for (long n = 0; n < c.N && shown < 24; ++n) {
+                    const double d = (double)C[m * c.N + n] - want[m * c.N + n];
+                    if (fabs(d) > 0.05 + 0.02 * fabs(want[m * c.N + n])) {
+                        printf("   m %ld n %ld got %.3f want %.3f\n", m, n, (double)C[m * c.N + n], want[m * c.N + n]);
+                        ++shown;
+                    }
+                }
+        }
+        const bool ok = rc == 0 && rel < 3e-3 && same && cpuhip_oob_reads == 0;
+        printf("%-34s bm %3d sched %2ld: rc %d rel-L2 %.2e %s%s%s\n", c.name, c.bm, sched, rc, rel,
+               same ? "" : "DIFFERS from schedule 0 ", cpuhip_oob_reads ? "reads past the tensor " : "", ok ? "ok" : "FAIL");
+        if (!ok) ++n_bad;
+    }
+}
+
+// 3x3 convolution (implicit GEMM, two concatenated sources, optional stride 2 / nearest-2x input) + bias + row vector
+static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, int Cout, int stride, int ups, int bm) {
+    using namespace vsxg;
+    const int ks = 3, pad = 1;
+    const int Hs = ups ? H / 2 : H, Ws = ups ? W / 2 : W;               // stored resolution of the sources
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    const long M = (long)nimg * Ho * Wo, K = (long)ks * ks * (C1 + C2);
+    auto X1 = randh((size_t)nimg * Hs * Ws * C1), X2 = randh((size_t)nimg * Hs * Ws * (C2 ? C2 : 1));
+    auto Wt = randh((size_t)Cout * K, 1.0f / sqrtf((float)K)), bias = randh(Cout), rowvec = randh((size_t)nimg * Cout);
+    auto Wp = pack_b(Wt, Cout, K);
+    std::vector<double> want((size_t)M * Cout);
+    for (int i = 0; i < nimg; ++i)
+        for (int ho = 0; ho < Ho; ++ho)
+            for (int wo = 0; wo < Wo; ++wo)
+                for (int co = 0; co < Cout; ++co) {
+                    double s = (double)bias[co] + (double)rowvec[(size_t)i * Cout + co];
+                    for (int kh = 0; kh < ks; ++kh)
+                        for (int kw = 0; kw < ks; ++kw) {
+                            const int h = ho * stride - pad + kh, w = wo * stride - pad + kw;
+                            if (h < 0 || h >= H || w < 0 || w >= W) continue;
+                            const int hs = ups ? h / 2 : h, wsrc = ups ? w / 2 : w;
+                            const half_t* wrow = Wt.data() + (size_t)co * K + (size_t)(kh * ks + kw) * (C1 + C2);
+                            const size_t pix = ((size_t)i * Hs + hs) * Ws + wsrc;
+                            for (int c = 0; c < C1; ++c) s += (double)X1[pix * C1 + c] * (double)wrow[c];
+                            for (int c = 0; c < C2; ++c) s += (double)X2[pix * C2 + c] * (double)wrow[C1 + c];
+                        }
+                    want[((size_t)(i * Ho + ho) * Wo + wo) * Cout + co] = s;
+                }
+    std::vector<half_t> first;
+    for (long sched : g_scheds) {
+        std::vector<half_t> C((size_t)M * Cout, (half_t)-7.f);
+        GemmParams p{};
+        p.A = X1.data(); p.A2 = C2 ? X2.data() : nullptr; p.B = sched >= 16 ? Wp.data() : Wt.data(); p.C = C.data();
+        p.bias = bias.data(); p.rowvec = rowvec.data(); p.rows_per_vec = (long)Ho * Wo;
+        p.M = M; p.N = Cout; p.K = K; p.ldb = K; p.ldc = Cout; p.batch1 = 1; p.alpha = 1.0f;
+        p.a_mode = 1; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.Ho = Ho; p.Wo = Wo; p.ks = ks; p.stride = stride;
+        p.ups = ups; p.pad = pad;
+        p.vec4 = p.vec8 = 1;
+        p.a_bytes = (unsigned)((size_t)nimg * Hs * Ws * C1 * 2);
+        p.a2_bytes = (unsigned)((size_t)nimg * Hs * Ws * C2 * 2);
+        p.b_bytes = (unsigned)((size_t)Cout * K * 2);
+        p.splitk = 1;
+        if (!pp_supported(p)) { printf("%s: not eligible\n", name); return; }
+        g_sched = sched;
+        cpuhip_oob_reads = 0;
+        const int rc = launch_pp(p, bm, nullptr);
+        double num = 0, den = 0;
+        for (size_t i = 0; i < want.size(); ++i) {
+            const double d = (double)C[i] - want[i];
+            num += d * d;
+            den += want[i] * want[i];
+        }
+        const double rel = sqrt(num / den);
+        bool same = true;
+        if (first.empty()) first = C;
+        else same = memcmp(first.data(), C.data(), C.size() * sizeof(half_t)) == 0;
+        const bool ok = rc == 0 && rel < 3e-3 && same && cpuhip_oob_reads == 0;
+        printf("%-34s bm %3d sched %2ld: rc %d rel-L2 %.2e %s%s%s\n", name, bm, sched, rc, rel,
+               same ? "" : "DIFFERS from the first schedule ", cpuhip_oob_reads ? "reads past the tensor " : "",
+               ok ? "ok" : "FAIL");
+        if (!ok) ++n_bad;
+    }
+}
+
+int main(int argc, char** argv) {
+    const Case cases[] = {
+        {"plain 256x320x64", 256, 320, 64, false, false, 256},                 // one tile, one slab
+        {"plain 640x320x192 (+res)", 640, 320, 192, true, false, 256},        // 3 tiles incl. a ragged one, 3 slabs
+        {"plain 1536x640x128", 1536, 640, 128, false, false, 256},            // 12 tiles on 8 workgroups: 2 tiles each
+        {"K tail 512x320x72", 512, 320, 72, true, false, 256},                // 2 slabs, the second 8 wide
+        {"geglu 512x160x128", 512, 160, 128, false, true, 256},
+        {"plain 384x320x64 (+res) 128-row", 384, 320, 64, true, false, 128},  // one slab per tile
+        {"geglu 300x320x192 128-row", 300, 320, 192, false, true, 128},
+    };
+    // usage: check_gemm_pp [case index | -1 = all] [comma-separated schedules]
+    const int only = argc > 1 ? atoi(argv[1]) : -1;
+    if (argc > 2) {
+        g_scheds.clear();
+        for (char* tok = strtok(argv[2], ","); tok; tok = strtok(nullptr, ",")) g_scheds.push_back(atol(tok));
+    }
+    const int ncases = (int)(sizeof(cases) / sizeof(cases[0]));
+    for (int i = 0; i < ncases; ++i)
+        if (only < 0 || only == i) run_case(cases[i]);
+    if (only < 0 || only == ncases) run_conv("conv3x3 2x8x8 64+64->320", 2, 8, 8, 64, 64, 320, 1, 0, 256);
+    if (only < 0 || only == ncases + 1) run_conv("conv3x3 3x12x8 128->320 /s2 128-row", 3, 12, 8, 128, 0, 320, 2, 0, 128);
+    if (only < 0 || only == ncases + 2) run_conv("conv3x3 2x8x8 64->320 nearest-2x", 2, 8, 8, 64, 0, 320, 1, 1, 128);
+    printf(n_bad ? "%d check(s) FAILED\n" : "all checks passed\n", n_bad);
+    return n_bad ? 1 : 0;
+}

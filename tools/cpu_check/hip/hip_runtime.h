@@ -23,7 +23,11 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
+#ifdef CPUHIP_DYNAMIC_LDS_ONLY        // the kernel only has `extern __shared__ smem[]`: see hip_gemm.h
+#define __shared__
+#else
 #define __shared__ static
+#endif
 #define __restrict__
 
 struct dim3 {
@@ -42,6 +46,8 @@ struct Ctx {
     std::barrier<>* block_bar = nullptr;
     std::barrier<>* wave_bar = nullptr;
     float* wave_slots = nullptr;
+    void* wave_scratch = nullptr;      // 64 KiB per wave for collective emulations (MFMA)
+    const void* kernarg = nullptr;     // the first kernel argument (what the kernarg segment starts with)
 };
 inline thread_local Ctx ctx;
 }  // namespace cpuhip
@@ -66,8 +72,12 @@ static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 using std::max;
 using std::min;
 
+template <typename A0, typename... Rest>
+const void* cpuhip_first(const A0& a0, const Rest&...) { return &a0; }
+
 template <typename K, typename... Args>
 void cpuhip_launch(K kernel, dim3 grid, dim3 block, Args... args) {
+    const void* kernarg = cpuhip_first(args...);
     const unsigned nthreads = block.x;
     const unsigned nwaves = (nthreads + 63) / 64;
     for (unsigned bz = 0; bz < grid.z; ++bz)
@@ -76,6 +86,7 @@ void cpuhip_launch(K kernel, dim3 grid, dim3 block, Args... args) {
                 std::barrier<> block_bar((std::ptrdiff_t)nthreads);
                 std::vector<std::unique_ptr<std::barrier<>>> wave_bars;
                 std::vector<std::vector<float>> slots(nwaves, std::vector<float>(64, 0.f));
+                std::vector<std::vector<unsigned char>> scratch(nwaves, std::vector<unsigned char>(65536));
                 for (unsigned w = 0; w < nwaves; ++w) {
                     const unsigned lanes = std::min(64u, nthreads - w * 64);
                     wave_bars.emplace_back(new std::barrier<>((std::ptrdiff_t)lanes));
@@ -91,6 +102,8 @@ void cpuhip_launch(K kernel, dim3 grid, dim3 block, Args... args) {
                         c.block_bar = &block_bar;
                         c.wave_bar = wave_bars[t / 64].get();
                         c.wave_slots = slots[t / 64].data();
+                        c.wave_scratch = scratch[t / 64].data();
+                        c.kernarg = kernarg;
                         kernel(args...);
                         // a thread that returns early must not leave the others waiting at a later barrier
                         block_bar.arrive_and_drop();

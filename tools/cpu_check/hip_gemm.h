@@ -1,0 +1,91 @@
+// Additions to hip/hip_runtime.h for the MFMA / LDS-DMA kernels (gemm_pp.hip): the gfx950 builtins they use, mapped to
+// host code with the hardware's data layout.
+//   * v_mfma_f32_32x32x16_f16: a wave-collective; lane l holds A[row l%32][k = 8*(l/32) .. +7], B[k = 8*(l/32) .. +7][col
+//     l%32] and D[row 8*(r/4) + 4*(l/32) + r%4][col l%32] in register r.
+//   * buffer_load_dwordx4 ... lds: lane l moves 16 bytes from base + voffset + soffset to LDS at (M0 base) + 16*l; the
+//     descriptor's range check looks at voffset only (+16 <= num_records), out of range reads as zero.  The harness ALSO
+//     checks that an in-range lane never reads beyond the allocation (on the GPU that would be a silent over-read).
+//   * s_barrier = workgroup barrier; sched_barrier = wave rendezvous (see below); waitcnt / setprio are no-ops (the emulated DMA is synchronous, so the
+//     ASYNCHRONOUS hazards of a schedule are not visible here — only whether every piece is issued exactly once, to the
+//     right place, from the right address).
+// Define CPUHIP_DYNAMIC_LDS_ONLY before including hip/hip_runtime.h.
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+// `extern __shared__ unsigned char smem[];` inside a kernel becomes a block-scope redeclaration of `cpuhip_smem`: the
+// harness defines that array (160 KiB, 16-byte aligned) in the namespace that encloses the kernel.
+#define smem cpuhip_smem
+#define CPUHIP_DEFINE_LDS alignas(16) unsigned char cpuhip_smem[160 * 1024];
+
+struct cpuhip_rsrc { const unsigned char* base; unsigned bytes; };
+inline long cpuhip_oob_reads = 0;
+#define __amdgpu_buffer_rsrc_t cpuhip_rsrc
+#define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, records, flags) \
+    cpuhip_rsrc{reinterpret_cast<const unsigned char*>(ptr), (unsigned)(records)}
+
+template <typename LdsPtr>
+static inline void cpuhip_buffer_load_lds(cpuhip_rsrc r, LdsPtr lds, int size, int voffset, int soffset, int ioffset, int) {
+    unsigned char* dst = (unsigned char*)(uintptr_t)lds + 16 * (cpuhip::ctx.tid.x & 63);
+    const unsigned long off = (unsigned long)(unsigned)voffset + (unsigned)ioffset;
+    if (size != 16) abort();
+    if (off + 16 > r.bytes) {
+        memset(dst, 0, 16);
+        return;
+    }
+    const unsigned long addr = off + (unsigned long)(unsigned)soffset;
+    if (addr + 16 > r.bytes) {                       // in range for the descriptor, but past the tensor
+        __atomic_add_fetch(&cpuhip_oob_reads, 1, __ATOMIC_RELAXED);
+        memset(dst, 0, 16);
+        return;
+    }
+    memcpy(dst, r.base + addr, 16);
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, size, voff, soff, ioff, aux) \
+    cpuhip_buffer_load_lds(rsrc, lds, size, voff, soff, ioff, aux)
+
+typedef _Float16 cpuhip_h8 __attribute__((ext_vector_type(8)));
+typedef float cpuhip_f16v __attribute__((ext_vector_type(16)));
+static inline cpuhip_f16v cpuhip_mfma_32x32x16(cpuhip_h8 a, cpuhip_h8 b, cpuhip_f16v c, int, int, int) {
+    struct Slot { cpuhip_h8 a, b; };
+    Slot* s = static_cast<Slot*>(cpuhip::ctx.wave_scratch);
+    const int l = (int)(cpuhip::ctx.tid.x & 63);
+    s[l].a = a;
+    s[l].b = b;
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    const int col = l & 31, hi = l >> 5;
+    cpuhip_f16v d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = 8 * (r >> 2) + 4 * hi + (r & 3);
+        float acc = 0.f;
+        for (int k = 0; k < 16; ++k) acc += (float)s[row + 32 * (k >> 3)].a[k & 7] * (float)s[col + 32 * (k >> 3)].b[k & 7];
+        d[r] += acc;
+    }
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) cpuhip_mfma_32x32x16(a, b, c, x, y, z)
+#define __builtin_amdgcn_s_barrier() (cpuhip::ctx.block_bar->arrive_and_wait())
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+// The 64 lanes of a wave run in lockstep on the hardware, so a wave may write LDS and read it back (other lanes' data)
+// without any barrier — the epilogue's staging area does.  Here the lanes are independent threads: every
+// scheduling barrier in the source (they sit exactly between such phases) doubles as a wave-wide rendezvous.
+#define __builtin_amdgcn_sched_barrier(x) (cpuhip::ctx.wave_bar->arrive_and_wait())
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_kernarg_segment_ptr() (const_cast<void*>(cpuhip::ctx.kernarg))
+
+// device queries of the launcher
+constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+inline int cpuhip_num_cus = 8;
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = cpuhip_num_cus; return hipSuccess; }
+
+// `asm volatile("s_waitcnt ...")` / `asm volatile("" : "+s"(x))`: AMDGPU text, meaningless here.  (Every system header this
+// translation unit needs is already included above.)
+#define asm
+#define volatile(...)
