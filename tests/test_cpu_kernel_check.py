@@ -58,3 +58,9 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900)
         print(r.stdout)
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # ordering hazards: the multi-tile, multi-slab case again with every DMA piece landing as LATE as the kernel's own
+    # waits allow (the default run above lands them at issue, the other extreme); see tools/cpu_check/hip_gemm.h
+    r = subprocess.run([exe, '1', '0,3,4,5,6,20'], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, CPUHIP_DMA='late'))
+    print(r.stdout)
+    assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

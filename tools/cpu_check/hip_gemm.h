@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include <type_traits>
+#include <vector>
 
 // `extern __shared__ unsigned char smem[];` inside a kernel becomes a block-scope redeclaration of `cpuhip_smem`: the
 // harness defines that array (160 KiB, 16-byte aligned) in the namespace that encloses the kernel.
@@ -26,22 +27,52 @@ inline long cpuhip_oob_reads = 0;
 #define __builtin_amdgcn_make_buffer_rsrc(ptr, stride, records, flags) \
     cpuhip_rsrc{reinterpret_cast<const unsigned char*>(ptr), (unsigned)(records)}
 
+// When does an LDS-DMA piece land?  Anywhere between its issue and the issuing wave's next `s_waitcnt vmcnt(0)`.  The
+// two extremes are emulated: CPUHIP_DMA=early (default) writes LDS at issue — a piece aimed at a ring slot that some wave
+// is still reading (write-after-read hazard) corrupts the result; CPUHIP_DMA=late keeps the 16 bytes in a per-lane queue
+// and writes them at the wave's wait — a piece issued after the wait that was supposed to cover it (read-before-landing)
+// leaves stale data in LDS.  A schedule that is correct under both has no ordering hazard in this model.
+struct cpuhip_pending { unsigned char* dst; unsigned char data[16]; };
+inline thread_local std::vector<cpuhip_pending> cpuhip_queue;
+static inline bool cpuhip_dma_late() {
+    static const bool late = getenv("CPUHIP_DMA") && !strcmp(getenv("CPUHIP_DMA"), "late");
+    return late;
+}
+static inline void cpuhip_land(unsigned char* dst, const unsigned char* src16) {
+    if (cpuhip_dma_late()) {
+        cpuhip_pending p;
+        p.dst = dst;
+        if (src16) memcpy(p.data, src16, 16); else memset(p.data, 0, 16);
+        cpuhip_queue.push_back(p);
+    } else if (src16) {
+        memcpy(dst, src16, 16);
+    } else {
+        memset(dst, 0, 16);
+    }
+}
+static inline void cpuhip_wait_vmcnt(int n) {       // all but the n most recent pieces of this lane have landed
+    const size_t keep = (size_t)n < cpuhip_queue.size() ? (size_t)n : cpuhip_queue.size();
+    const size_t done = cpuhip_queue.size() - keep;
+    for (size_t i = 0; i < done; ++i) memcpy(cpuhip_queue[i].dst, cpuhip_queue[i].data, 16);
+    cpuhip_queue.erase(cpuhip_queue.begin(), cpuhip_queue.begin() + (long)done);
+}
+
 template <typename LdsPtr>
 static inline void cpuhip_buffer_load_lds(cpuhip_rsrc r, LdsPtr lds, int size, int voffset, int soffset, int ioffset, int) {
     unsigned char* dst = (unsigned char*)(uintptr_t)lds + 16 * (cpuhip::ctx.tid.x & 63);
     const unsigned long off = (unsigned long)(unsigned)voffset + (unsigned)ioffset;
     if (size != 16) abort();
     if (off + 16 > r.bytes) {
-        memset(dst, 0, 16);
+        cpuhip_land(dst, nullptr);
         return;
     }
     const unsigned long addr = off + (unsigned long)(unsigned)soffset;
     if (addr + 16 > r.bytes) {                       // in range for the descriptor, but past the tensor
         __atomic_add_fetch(&cpuhip_oob_reads, 1, __ATOMIC_RELAXED);
-        memset(dst, 0, 16);
+        cpuhip_land(dst, nullptr);
         return;
     }
-    memcpy(dst, r.base + addr, 16);
+    cpuhip_land(dst, r.base + addr);
 }
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, size, voff, soff, ioff, aux) \
     cpuhip_buffer_load_lds(rsrc, lds, size, voff, soff, ioff, aux)
@@ -86,6 +117,14 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = cpuhip_num_cus; return hipSuccess; }
 
 // `asm volatile("s_waitcnt ...")` / `asm volatile("" : "+s"(x))`: AMDGPU text, meaningless here.  (Every system header this
-// translation unit needs is already included above.)
+// translation unit needs is already included above.)  gemm_common.h's wait_vmcnt<N>() is renamed away and replaced by
+// one that lands the queued DMA pieces (CPUHIP_GEMM_COMMON_INCLUDED: include gemm_common.h through this header).
 #define asm
 #define volatile(...)
+#define wait_vmcnt cpuhip_unused_wait_vmcnt
+#include "gemm_common.h"
+#undef wait_vmcnt
+namespace vsxg {
+template <int N>
+inline void wait_vmcnt() { cpuhip_wait_vmcnt(N); }
+}
