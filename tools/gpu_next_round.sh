@@ -33,3 +33,5 @@ tail -n 2 $O/${TAG}_next_sched_b1.txt | cut -c1-250
 # ---- gradient path / training step on the development library's backward kernels ----
 ( VSX_LIB_VARIANT=next timeout 300 python -m pytest tests/test_autograd.py tests/test_training.py -m gpu -q -s -rf ) > $O/${TAG}_next_training.log 2>&1
 grep -E "loss:|worst cosine|level|passed|failed" $O/${TAG}_next_training.log | cut -c1-200
+VSX_LIB_VARIANT=next timeout 300 python tools/train_bench.py --frames 16 --latent 64 --steps 2 > $O/${TAG}_next_train_bench.txt 2>&1
+tail -n 4 $O/${TAG}_next_train_bench.txt | cut -c1-250
