@@ -28,6 +28,8 @@ VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 2 --rounds 4 --
 tail -n 3 $O/${TAG}_next_sched_b2.txt | cut -c1-250
 VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 2 --rounds 4 --scheds 0,4,16,20 --bpack > $O/${TAG}_next_bpack_b2.txt 2>&1
 tail -n 3 $O/${TAG}_next_bpack_b2.txt | cut -c1-250
+VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 2 --rounds 3 --scheds 0,4,32,36,64,68 > $O/${TAG}_next_diag_b2.txt 2>&1
+tail -n 3 $O/${TAG}_next_diag_b2.txt | cut -c1-250
 VSX_LIB_VARIANT=next timeout 300 python tools/gemm_ab.py --batch 1 --rounds 4 --scheds 0,3,4,5,6 > $O/${TAG}_next_sched_b1.txt 2>&1
 tail -n 2 $O/${TAG}_next_sched_b1.txt | cut -c1-250
 # ---- gradient path / training step on the development library's backward kernels ----

@@ -227,7 +227,10 @@ constexpr int sched_end(const int sched, const int npiece, const int slot) {    
 
 // TM: 32-row blocks per wave (tile = 128*TM x 320).  CONV: implicit-GEMM A loader (a_mode 1) or plain row-major A.
 // BPACK: B is stored piece-major (see the header); else row-major [N, ldb].
-template <int TM, bool CONV, int SCHED, bool BPACK>
+// DIAG (measurement only, results are garbage): 1 = the MFMAs are left out (fragments are still read: what the operand
+// stream + LDS traffic cost alone), 2 = no DMA piece is issued (what MFMAs + fragment reads + barriers cost alone).
+// pp_sched + 32 / + 64 select them; tools/gemm_ab.py lists them next to the real variants.
+template <int TM, bool CONV, int SCHED, bool BPACK, int DIAG = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused, const int tiles_total) {
     constexpr int TN = 5;
     constexpr int BM = 128 * TM, BN = 320;
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         if (++i_kt == nk) { i_kt = 0; ++i_t; need_setup = true; }
     };
     auto issue_piece = [&](const int q) {           // q is a compile-time constant at every call site
+        if constexpr (DIAG == 2) return;
         if (q < GA) {
             const int kofs = (q & 1) ? kofs_o : kofs_e;             // wave * GA is even
             lptr_t dst = (lptr_t)(smem + i_sb + (wave * GA + q) * 1024);
@@ -436,7 +440,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         for (int j = 0; j < TN; ++j)
             bf[j] = *reinterpret_cast<const h8*>(smem + slot_off + ((b_addr ^ (ks * 32)) + j * 4096));
     };
+    auto keep_fragments = [&]() {               // DIAG 1: the fragment reads must survive without their consumer
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[j]));
+    };
     auto mma = [&]() {
+        if constexpr (DIAG == 1) {
+            keep_fragments();
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -445,6 +459,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     };
     auto mma_first = [&]() {                    // first k-step of a tile: C = 0 (inline constant, no zero-fill pass)
         const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (DIAG == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j][i] = zero;
+            keep_fragments();
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -461,7 +483,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const int i = m / TN, j = m % TN;
-            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], FIRST ? zero : acc[j][i], 0, 0, 0);
+            if constexpr (DIAG == 1) {
+                if (FIRST) acc[j][i] = zero;
+                if (m == 0) keep_fragments();
+            } else {
+                acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], FIRST ? zero : acc[j][i], 0, 0, 0);
+            }
 #pragma unroll
             for (int q = 0; q < NPIECE; ++q)
                 if (q >= lo && q < hi_ && ((q - lo + 1) * NM) / (n + 1) - 1 == m) {
@@ -563,14 +590,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     if (G == 0) bar();                          // matches group 1's extra barrier at the start
 }
 
-template <int TM, bool CONV, int SCHED, bool BPACK = false>
+template <int TM, bool CONV, int SCHED, bool BPACK = false, int DIAG = 0>
 int launch_one(const GemmParams& p, hipStream_t stream) {
     constexpr size_t stage = (size_t)(128 * TM + 320) * 128;
     constexpr size_t smem = 2 * stage + (8 - stage / EP_BYTES) * EP_BYTES;     // ring + the staging areas behind it
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TM, CONV, SCHED, BPACK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TM, CONV, SCHED, BPACK, DIAG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -584,7 +611,7 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = p.tiles_total < n_cu ? p.tiles_total : n_cu;      // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm_pp_kernel<TM, CONV, SCHED, BPACK>), dim3((unsigned)grid), dim3(512), smem, stream, p,
+    hipLaunchKernelGGL((gemm_pp_kernel<TM, CONV, SCHED, BPACK, DIAG>), dim3((unsigned)grid), dim3(512), smem, stream, p,
                        p.tiles_total);
     return vsx_check_launch("vsx_gemm_f16 (persistent)");
 }
@@ -612,9 +639,20 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     p.tiles_total = (int)(((p.M + bm - 1) / bm) * p.tiles_n);
     // option "pp_sched" (env VSX_PP_SCHED) selects the piece schedule (row of SCHEDS) among the compiled variants
     const long opt = gemm_option("pp_sched");
-    const bool bpack = opt >= 16 && opt < 32;               // + 16: the caller passes a piece-major (packed) B operand
+    const bool bpack = (opt & 16) != 0 && opt < 32;         // + 16: the caller passes a piece-major (packed) B operand
     const int variant = (opt & 15) < NSCHED ? (int)(opt & 15) : 0;
     const bool conv = p.a_mode == 1;
+    if (opt >= 32) {                                        // measurement variants (256-row tiles, schedules 0 and 4)
+        const int diag = opt >= 64 ? 2 : 1;
+        if (bm != 256 || (variant != 0 && variant != 4))
+            return vsx_fail(VSX_E_UNSUPPORTED, "gemm_pp: the diagnostic variants exist for 256-row tiles, schedules 0 and 4");
+        if (diag == 1) {
+            if (variant == 4) return conv ? launch_one<2, true, 4, false, 1>(p, stream) : launch_one<2, false, 4, false, 1>(p, stream);
+            return conv ? launch_one<2, true, 0, false, 1>(p, stream) : launch_one<2, false, 0, false, 1>(p, stream);
+        }
+        if (variant == 4) return conv ? launch_one<2, true, 4, false, 2>(p, stream) : launch_one<2, false, 4, false, 2>(p, stream);
+        return conv ? launch_one<2, true, 0, false, 2>(p, stream) : launch_one<2, false, 0, false, 2>(p, stream);
+    }
     if (bpack) {
         if (p.K % BK != 0 || p.ldb != p.K)
             return vsx_fail(VSX_E_UNSUPPORTED, "gemm_pp: a packed B operand needs K %% 64 == 0 and ldb == K");
