@@ -195,3 +195,43 @@ def test_train_flow_from_the_option_file_then_test_with_the_trained_adapter(dumm
         assert set(edited) == {'kitten_to_catA', 'kitten_to_dogB', 'kitten_to_dogA'}
     finally:
         os.chdir(cwd)
+
+
+def test_noise_schedule_and_lr_schedules_closed_forms():
+    """DDPM add_noise / get_velocity and the learning-rate schedules the option files can name (diffusers
+    `get_scheduler`): closed forms."""
+    import math
+    from oracle import training as otrain
+    from videoswap_amd.compat import SD15_SCHEDULER_CONFIG, DDPMScheduler
+    from videoswap_amd.runner import get_scheduler
+    sched = DDPMScheduler(**{k: SD15_SCHEDULER_CONFIG[k] for k in ('num_train_timesteps', 'beta_start', 'beta_end',
+                                                                   'beta_schedule')})
+    acp = otrain.alphas_cumprod()
+    assert torch.allclose(sched.alphas_cumprod, acp)
+    g = torch.Generator().manual_seed(0)
+    x, n = torch.randn(2, 4, 3, 5, 5, generator=g), torch.randn(2, 4, 3, 5, 5, generator=g)
+    t = torch.tensor([10, 900])
+    assert torch.allclose(sched.add_noise(x, n, t), otrain.add_noise(x, n, t, acp))
+    v = sched.get_velocity(x, n, t)
+    a = acp[t].view(-1, 1, 1, 1, 1)
+    assert torch.allclose(v, a.sqrt() * n - (1 - a).sqrt() * x)
+    # x0 is recovered from (x_t, v): x0 = sqrt(a) x_t - sqrt(1 - a) v
+    xt = sched.add_noise(x, n, t)
+    assert torch.allclose(a.sqrt() * xt - (1 - a).sqrt() * v, x, atol=1e-5)
+
+    def lrs(name, warm, total, steps):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=1.0)
+        s = get_scheduler(name, opt, warm, total)
+        out = []
+        for _ in range(steps):
+            out.append(s.get_last_lr()[0])
+            opt.step()
+            s.step()
+        return out
+    assert lrs('constant', 0, 10, 4) == [1.0] * 4
+    assert lrs('constant_with_warmup', 4, 10, 6) == [0.0, 0.25, 0.5, 0.75, 1.0, 1.0]
+    lin = lrs('linear', 2, 10, 11)
+    assert lin[:3] == [0.0, 0.5, 1.0] and abs(lin[6] - 0.5) < 1e-9 and lin[10] == 0.0
+    cos = lrs('cosine', 0, 8, 9)
+    assert abs(cos[4] - 0.5) < 1e-9 and abs(cos[2] - 0.5 * (1 + math.cos(math.pi * 0.25))) < 1e-9 and cos[8] < 1e-9
