@@ -187,3 +187,20 @@ def test_strided_alltoall_layouts_of_the_site_reshard(world):
     back = _simulate_alltoall(sites, B, f, blk, *to_frames, out_numel=B * f * HW * C)
     for r in range(world):
         assert torch.equal(back[r], local[r]), r
+
+
+def _grad_allreduce(rank, world):
+    """What DDP does for the adapter's 1.1 M parameters in the training step: mean of the gradients over the ranks."""
+    from videoswap_amd.trainer import VideoSwapTrainer
+    torch.manual_seed(3)
+    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
+    base = [torch.randn(5, 3), torch.randn(7)]
+    for p, b in zip(params, base):
+        p.grad = b * (rank + 1)
+    VideoSwapTrainer._all_reduce_gradients(params)
+    mean = sum(range(1, world + 1)) / world
+    return all(torch.allclose(p.grad, b * mean) for p, b in zip(params, base))
+
+
+def test_adapter_gradient_allreduce():
+    assert all(_run(_grad_allreduce))
