@@ -37,3 +37,6 @@ tail -n 2 $O/${TAG}_next_sched_b1.txt | cut -c1-250
 grep -E "loss:|worst cosine|level|passed|failed" $O/${TAG}_next_training.log | cut -c1-200
 VSX_LIB_VARIANT=next timeout 300 python tools/train_bench.py --frames 16 --latent 64 --steps 2 > $O/${TAG}_next_train_bench.txt 2>&1
 tail -n 4 $O/${TAG}_next_train_bench.txt | cut -c1-250
+# ---- do MFMA and VALU work of different waves overlap on a SIMD?  (decides whether a warp-specialised attention pays) ----
+( cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_valu mfma_valu.hip && timeout 60 /tmp/mfma_valu ) > $O/${TAG}_mfma_valu.txt 2>&1
+tail -n 4 $O/${TAG}_mfma_valu.txt | cut -c1-250
