@@ -8,6 +8,7 @@ of the kernels (one fp16 rounding per op output) but none of their code.  The ke
 PyTorch references on the GPU (tests/test_kernels_gpu.py); what this file makes testable on CPU is everything AROUND
 them.  Use `with host_emulation.installed():`; tests marked `device` get it from tests/conftest.py when there is no GPU."""
 import contextlib
+import functools
 import math
 
 import torch
@@ -335,9 +336,19 @@ def installed():
     """Swap the kernel table of videoswap_amd.ops (`ops._raw`) for the functions above (and back)."""
     from videoswap_amd import ops
     saved = dict(ops._raw)
+
+    def kernel_like(fn):
+        # a real kernel function writes into torch.empty buffers: its result carries no autograd history.  The
+        # stand-ins are plain PyTorch, so they run under no_grad — a gradient can then only come from
+        # videoswap_amd/autograd.py, exactly as on the GPU
+        @functools.wraps(fn)
+        def run(*a, **k):
+            with torch.no_grad():
+                return fn(*a, **k)
+        return run
     try:
         for n in _NAMES:
-            ops._raw[n] = globals()[n]
+            ops._raw[n] = kernel_like(globals()[n])
         yield ops
     finally:
         ops._raw.clear()

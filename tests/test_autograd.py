@@ -76,6 +76,24 @@ def test_linear_weight_gradient_for_the_adapter_mlp():
     check(b.grad, br.grad, what='db')
 
 
+def test_linear_records_when_only_weight_and_bias_need_a_gradient():
+    """The adapter's first Linear: its input (the point embedding) carries NO grad, its weight and bias are the trainable
+    parameters (adapter_model.py:70-107).  The call must still go through the gradient path — a raw kernel call returns
+    a tensor without history and the whole training step would have nothing to differentiate."""
+    x0, w0, b0, g0 = rnd(6, 64, seed=6), rnd(32, 64, seed=7, scale=0.2), rnd(32, seed=8), rnd(6, 32, seed=9)
+    x = x0.to(DEV, torch.float16)                     # not a leaf that requires grad
+    w, b = leaf(w0), leaf(b0)
+    y = ops().linear(x, w, b)
+    assert y.requires_grad and y.grad_fn is not None
+    (y.float() * g0.to(DEV)).sum().backward()
+    wr, br = ref_leaf(w0), ref_leaf(b0)
+    (F.linear(x0.half().float(), wr, br) * g0).sum().backward()
+    check(w.grad, wr.grad, what='dw')
+    check(b.grad, br.grad, what='db')
+    y2 = ops().linear(x, w, bias=b)                   # bias by keyword
+    assert y2.requires_grad
+
+
 def conv_ref(x, w, b, stride, x2, ups):
     xin = x if x2 is None else torch.cat([x, x2], -1)
     xin = xin.permute(0, 3, 1, 2)

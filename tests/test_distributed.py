@@ -190,16 +190,27 @@ def test_strided_alltoall_layouts_of_the_site_reshard(world):
 
 
 def _grad_allreduce(rank, world):
-    """What DDP does for the adapter's 1.1 M parameters in the training step: mean of the gradients over the ranks."""
+    """What DDP does for the adapter's 1.1 M parameters in the training step — mean of the gradients over the ranks —
+    and what a GradScaler must do on several ranks: ONE skip / step decision.  Step 1: rank 1 alone overflows, and one
+    parameter has no gradient on rank 0 only (fixed parameter list); every rank must skip and halve its scale without
+    hanging.  Step 2: finite everywhere -> the mean gradient reaches the optimizer on every rank."""
     from videoswap_amd.trainer import VideoSwapTrainer
     torch.manual_seed(3)
-    params = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
+    adapter = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))])
     base = [torch.randn(5, 3), torch.randn(7)]
-    for p, b in zip(params, base):
-        p.grad = b * (rank + 1)
-    VideoSwapTrainer._all_reduce_gradients(params)
+    tr = object.__new__(VideoSwapTrainer)
+    tr.adapter, tr.accelerator, tr.lr_scheduler = adapter, None, None
+    tr.optimizer = torch.optim.SGD(adapter.parameters(), lr=1.0)
+    tr.loss_scale, tr.growth_interval, tr._clean_steps, tr.skipped_steps = 4.0, 2000, 0, 0
+
+    def loss_with(grads):       # a scalar whose gradient with respect to parameter i is grads[i] (None: not in the graph)
+        return sum((p * g).sum() for p, g in zip(adapter, grads) if g is not None)
+    bad = [base[0] * float('inf') if rank == 1 else base[0], None if rank == 0 else base[1]]
+    applied = tr.backward_and_update(loss_with(bad))
+    ok = (not applied) and tr.loss_scale == 2.0 and tr.skipped_steps == 1 and all(float(p.abs().sum()) == 0 for p in adapter)
+    applied = tr.backward_and_update(loss_with([b * (rank + 1) for b in base]))
     mean = sum(range(1, world + 1)) / world
-    return all(torch.allclose(p.grad, b * mean) for p, b in zip(params, base))
+    return ok and applied and all(torch.allclose(p.detach(), -b * mean, atol=1e-6) for p, b in zip(adapter, base))
 
 
 def test_adapter_gradient_allreduce():

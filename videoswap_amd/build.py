@@ -63,17 +63,23 @@ def source_digest(variant=None):
     return _digest(variant)
 
 
+_MARKER = b'@vsx-source-digest:'
+
+
 def built_digest(variant=None):
-    """Digest embedded in the existing libvsx.so, or None (missing / predates the symbol)."""
-    if not os.path.exists(lib_path(variant)):
+    """Digest embedded in the existing libvsx.so, or None (missing / predates the marker).  Read from the file's bytes,
+    not through dlopen: ctypes never unloads, so probing a stale library in this process would pin the old image
+    under its name and the library rebuilt right after would still answer with the old digest."""
+    path = lib_path(variant)
+    if not os.path.exists(path):
         return None
-    import ctypes
-    try:
-        fn = ctypes.CDLL(lib_path(variant)).vsx_source_digest
-    except (OSError, AttributeError):
+    with open(path, 'rb') as f:
+        blob = f.read()
+    i = blob.find(_MARKER)
+    if i < 0:
         return None
-    fn.restype = ctypes.c_char_p
-    return fn().decode()
+    j = blob.find(b'\0', i)
+    return blob[i + len(_MARKER):j].decode(errors='replace')
 
 
 def _compile(src, digest, variant=None):

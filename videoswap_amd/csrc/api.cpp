@@ -28,5 +28,8 @@ int vsx_check_launch(const char* what) {
 extern "C" int vsx_abi_version(void) { return VSX_ABI_VERSION; }
 // sha256 of csrc/ + include/vsx.h + the compiler flags this binary was built from (videoswap_amd/build.py): the
 // loader refuses a library whose digest differs from the sources next to it (stale kernels after a pull).
-extern "C" const char* vsx_source_digest(void) { return VSX_SOURCE_DIGEST; }
+// The string is stored behind a marker so that build.py can read it from the FILE (no dlopen: a stale image that was
+// loaded once stays mapped by name, and the rebuilt library would then report the old digest).
+static const char g_digest[] = "@vsx-source-digest:" VSX_SOURCE_DIGEST;
+extern "C" const char* vsx_source_digest(void) { return g_digest + 19; }
 extern "C" const char* vsx_last_error(void) { return g_err; }

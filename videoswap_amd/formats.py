@@ -27,9 +27,23 @@ class FormatError(ValueError):
 
 
 def _load(path):
+    """Every container read here (TAP, adapter, ED-LoRA, motion module, SD weights) is tensors / dicts / lists / strings:
+    it loads under `weights_only=True`, which refuses to unpickle arbitrary objects.  VSX_UNSAFE_PICKLE=1 opts into the
+    reference's behaviour (a bare torch.load, test.py:60-70) for a checkpoint that carries anything else."""
     if not os.path.isfile(path):
         raise FormatError(f'{path} does not exist')
-    return torch.load(path, map_location='cpu', weights_only=False)
+    if os.environ.get('VSX_UNSAFE_PICKLE') == '1':
+        return torch.load(path, map_location='cpu', weights_only=False)
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as e:
+        raise FormatError(f'{path}: not a plain tensor container ({type(e).__name__}: {str(e)[:200]}); '
+                          f'VSX_UNSAFE_PICKLE=1 loads it with full unpickling') from e
+
+
+def load_checkpoint(path):
+    """A state dict / tensor container from disk (motion module .ckpt, adapter.pth)."""
+    return _load(path)
 
 
 # ------------------------------------------------------------------------------------------------

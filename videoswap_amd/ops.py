@@ -606,9 +606,11 @@ def adapter_gather(tracks, selected, dmap, rate, out_scale=1.0):
 # torch.autograd.Function of videoswap_amd/autograd.py, whose backward is again built from kernel functions.
 _raw = {}
 
-# op name -> positions / keywords of the activation arguments whose requires_grad switches the gradient path on
+# op name -> positions / keywords of the arguments whose requires_grad switches the gradient path on: the activation
+# arguments, and for `linear` also weight and bias (the adapter's MLPs are the trainable parameters of the training step:
+# their first Linear gets an input WITHOUT grad — the point embedding — and must still record, adapter_model.py:70-107)
 _ACTIVATIONS = {
-    'linear': ((0,), ('residual',)), 'linear_vt': ((0,), ()), 'conv2d': ((0,), ('x2', 'residual')),
+    'linear': ((0, 1, 2), ('weight', 'bias', 'residual')), 'linear_vt': ((0,), ()), 'conv2d': ((0,), ('x2', 'residual')),
     'attention': ((0, 1, 2), ()), 'temporal_attention': ((0, 1, 2), ()), 'attention_scores': ((0, 1), ()),
     'attention_pv': ((0, 1), ()), 'head_scores': ((0, 1), ()), 'group_norm': ((0,), ('x2',)), 'layer_norm': ((0,), ()),
     'silu': ((0,), ()), 'quick_gelu': ((0,), ()), 'axpy': ((0, 1), ()), 'pack_latents': ((0,), ()),

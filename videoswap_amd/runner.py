@@ -36,30 +36,40 @@ def set_seed(seed):
         torch.cuda.manual_seed_all(seed)
 
 
+def _weight_dtype(opt, unet_cls):
+    """`mixed_precision` of the option file -> dtype of the frozen models.  The HIP kernels compute in fp16 storage /
+    fp32 accumulate and nothing else: with the product's UNet class anything but 'fp16' is refused HERE (test.py:73-75
+    would cast to fp32 and the first kernel call would fail deep inside the forward)."""
+    mixed = opt.get('mixed_precision', 'no')
+    dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(mixed, torch.float32)
+    if dtype != torch.float16 and unet_cls.__module__.startswith('videoswap_amd.'):
+        raise ValueError(f"mixed_precision: {mixed!r} is not supported by the MI355X kernels (fp16 storage, fp32 "
+                         f"accumulation); set `mixed_precision: fp16` in the option file")
+    return dtype
+
+
 def build_from_options(opt, device='cuda', classes=None):
     """test.py:45-91 — returns (pipeline, adapter, weight_dtype).  `classes` may override the model classes by
     registry name (tests run the same orchestration on the CPU oracle)."""
     classes = classes or {}
-    mixed = opt.get('mixed_precision', 'no')
-    weight_dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(mixed, torch.float32)
-
     unet_opt = dict(opt['models']['unet'])
     unet_type = unet_opt.pop('type')
     if unet_type != 'AnimateDiffUNet3DModel':
         raise NotImplementedError(unet_type)
     unet_cls = classes.get(unet_type) or build_model(unet_type)
+    weight_dtype = _weight_dtype(opt, unet_cls)
     kwargs = OmegaConf.to_container(OmegaConf.load(unet_opt.pop('inference_config_path')).unet_additional_kwargs)
     unet = unet_cls.from_pretrained_2d(opt['path']['pretrained_model_path'], subfolder='unet',
                                        unet_additional_kwargs=kwargs)
     if unet_opt.get('motion_module_path'):
-        sd = formats.rename_motion_module_keys(torch.load(unet_opt['motion_module_path'], map_location='cpu'))
+        sd = formats.rename_motion_module_keys(formats.load_checkpoint(unet_opt['motion_module_path']))
         unet.load_state_dict(sd, strict=False)
 
     adapter_opt = dict(opt['models']['adapter'])
     adapter_type = adapter_opt.pop('type')
     adapter_cls = classes.get(adapter_type) or build_model(adapter_type)
     adapter = adapter_cls(**OmegaConf.to_container(OmegaConf.load(adapter_opt['model_config_path'])))
-    adapter.load_state_dict(torch.load(opt['path']['pretrained_adapter_path'], map_location='cpu'))
+    adapter.load_state_dict(formats.load_checkpoint(opt['path']['pretrained_adapter_path']))
     adapter = adapter.to(dtype=weight_dtype)
 
     pipe_cls = classes.get(opt['val']['val_pipeline']) or build_pipeline(opt['val']['val_pipeline'])
@@ -152,7 +162,7 @@ def train(root_path, opt, opt_path, device='cuda', classes=None, max_iters=None)
         opt['manual_seed'] = random.randint(1, 10000)
     set_seed(opt['manual_seed'])
     sd_dir = opt['path']['pretrained_model_path']
-    weight_dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(opt.get('mixed_precision', 'no'), torch.float32)
+    weight_dtype = _weight_dtype(opt, classes.get('AnimateDiffUNet3DModel') or build_model('AnimateDiffUNet3DModel'))
 
     tokenizer = load_tokenizer(sd_dir)
     text_encoder = CLIPTextModel.from_pretrained(sd_dir, subfolder='text_encoder', torch_dtype=weight_dtype)
@@ -164,7 +174,7 @@ def train(root_path, opt, opt_path, device='cuda', classes=None, max_iters=None)
     kwargs = OmegaConf.to_container(OmegaConf.load(unet_opt.pop('inference_config_path')).unet_additional_kwargs)
     unet = (classes.get(unet_type) or build_model(unet_type)).from_pretrained_2d(
         sd_dir, subfolder='unet', unet_additional_kwargs=kwargs)
-    sd = formats.rename_motion_module_keys(torch.load(unet_opt['motion_module_path'], map_location='cpu'))
+    sd = formats.rename_motion_module_keys(formats.load_checkpoint(unet_opt['motion_module_path']))
     unet.load_state_dict(sd, strict=False)
     adapter_opt = dict(opt['models']['adapter'])
     adapter_type = adapter_opt.pop('type')

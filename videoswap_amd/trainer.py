@@ -101,13 +101,22 @@ class VideoSwapTrainer(VideoSwapPipeline):
             self.optimizer.zero_grad()
             return True
         (loss * self.loss_scale).backward()
-        params = [p for p in self.adapter.parameters() if p.grad is not None]
-        finite = all(bool(torch.isfinite(p.grad).all()) for p in params)
+        # every rank must take the SAME skip / step decision (and keep the same loss scale): the scaled gradients of a
+        # FIXED parameter list (missing gradients as zeros) are averaged first, finiteness is tested on the reduced
+        # buffer — an inf / nan on one rank reaches all of them through the sum
+        params = [p for p in self.adapter.parameters() if p.requires_grad]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+        self._all_reduce_mean(flat)
+        finite = bool(torch.isfinite(flat).all())
         if finite:
-            inv = 1.0 / self.loss_scale
+            flat.mul_(1.0 / self.loss_scale)
+            o = 0
             for p in params:
-                p.grad.mul_(inv)
-            self._all_reduce_gradients(params)
+                n = p.numel()
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(flat[o:o + n].view_as(p))
+                o += n
             # trainer_videoswap.py:96-97 clips the UNet's parameters, which have no gradient: kept as the no-op it is
             self.optimizer.step()
             if self.lr_scheduler is not None:
@@ -123,18 +132,12 @@ class VideoSwapTrainer(VideoSwapPipeline):
         return finite
 
     @staticmethod
-    def _all_reduce_gradients(params):
+    def _all_reduce_mean(flat):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
         dist.all_reduce(flat)
         flat.div_(dist.get_world_size())
-        o = 0
-        for p in params:
-            n = p.grad.numel()
-            p.grad.copy_(flat[o:o + n].view_as(p.grad))
-            o += n
 
     # ---- trainer_videoswap.py:33-97 ---------------------------------------------------------------------------------
     def step(self, batch=None):
