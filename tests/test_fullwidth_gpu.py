@@ -45,6 +45,10 @@ def _record(name, **kw):
 
 @pytest.fixture(scope='module')
 def models():
+    return build_models()
+
+
+def build_models():
     """Everything is built ON the device (seeded generator of videoswap_amd.synthetic: seconds instead of the minute
     a CPU initialisation of 860 M parameters takes); the oracle copies receive the product's fp16-exact weights."""
     from oracle import unet3d
