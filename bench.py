@@ -39,7 +39,15 @@ def parse():
     ap.add_argument('--frames', type=int, default=16)
     ap.add_argument('--latent', type=int, default=64)
     ap.add_argument('--ddim-steps', type=int, default=50)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3),
+                    help='BASELINE.json configs[1] (default; the headline: plain text embedding, no adapter, no '
+                         'controller) or configs[2]: the full swap path through VideoSwapPipeline.validation — AttentionStore '
+                         'during the inversion, ED-LoRA merge + per-layer embeddings [2,16,77,768], adapter residuals for '
+                         'the first half of the sampling steps, AttentionRefine + two SpatialBlenders (use_blend: true)')
+    ap.add_argument('--latent-h', type=int, default=0, help='latent height (default: --latent); 56 with --latent-w 96 = the '
+                    '448x768 frames of 26 of the 30 reference option files')
+    ap.add_argument('--latent-w', type=int, default=0)
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip both baseline legs (CPU port, torch-ROCm eager)')
     ap.add_argument('--prof-samples', type=int, default=400000)
     # hipEvent pairs around every 7th vsx_gemm_f16 launch (7 is coprime with the ~470 GEMM launches of a UNet call, so
     # every shape is sampled over the 100 calls of a clip); bracketing EVERY launch costs 5 % of the loop
@@ -52,7 +60,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_pipeline(device, frames):
+def build_pipeline(device, frames, swap=False):
     from videoswap_amd.compat import SD15_SCHEDULER_CONFIG, DDIMScheduler
     from videoswap_amd.pipeline import VideoSwapPipeline
     from videoswap_amd.synthetic import synth_weights_
@@ -62,27 +70,92 @@ def build_pipeline(device, frames):
     with torch.device(device):
         unet = AnimateDiffUNet3DModel(**cfg)
     unet = synth_weights_(unet, seed=1234).half().eval()
-    pipe = VideoSwapPipeline(unet=unet, scheduler=DDIMScheduler(**SD15_SCHEDULER_CONFIG))
+    extra = {}
+    if swap:        # configs[2]: point adapter, (synthetic) tokenizer / text encoder for the P2P word bookkeeping
+        from videoswap_amd.adapter import SparsePointAdapter
+        from videoswap_amd.synthetic import SyntheticTextEncoder, WhitespaceTokenizer
+        with torch.device(device):
+            adapter = SparsePointAdapter(embedding_channels=1280, channels=list(cfg['block_out_channels']))
+        extra = dict(adapter=synth_weights_(adapter, seed=3).half().eval(), tokenizer=WhitespaceTokenizer(),
+                     text_encoder=SyntheticTextEncoder(dim=768, dtype=torch.float16, device=device))
+    pipe = VideoSwapPipeline(unet=unet, scheduler=DDIMScheduler(**SD15_SCHEDULER_CONFIG), **extra)
     pipe.to(device)
     return pipe
 
 
-def one_clip(pipe, data, ddim_steps):
+SWAP_SOURCE = 'a silver jeep driving down a curvy road in the countryside'
+
+
+def synthetic_edlora(state_dict, rank=4, seed=4):
+    """rank-4 LoRA factors N(0, 0.01^2) on the keys convert_edlora_to_diffusers.py:46-53 merges, two new
+    concept tokens with 16 per-layer embeddings each."""
+    g = torch.Generator().manual_seed(seed)
+    lora = {}
+    for k, w in state_dict.items():
+        if (k.endswith(('to_q.weight', 'to_k.weight', 'to_v.weight', 'to_out.0.weight', 'ff.net.0.proj.weight',
+                        'ff.net.2.weight', 'proj_in.weight', 'proj_out.weight'))
+                and 'motion_modules' not in k and 'attentions' in k):
+            down = torch.randn(rank, w.shape[1], generator=g) * 0.01
+            up = torch.randn(w.shape[0], rank, generator=g) * 0.01
+            if w.dim() == 4:
+                down, up = down[:, :, None, None], up[:, :, None, None]
+            lora[k[:-6] + 'lora_down.weight'], lora[k[:-6] + 'lora_up.weight'] = down, up
+    emb = {'<porsche1>': torch.zeros(16, 768), '<porsche2>': torch.zeros(16, 768)}
+    return {'params': {'new_concept_embedding': emb, 'unet': lora}}
+
+
+def swap_clip(pipe, data, ddim_steps, lora, marks=None):
+    """configs[2], one clip through the reference's own orchestration (pipeline_videoswap.py:272-423 = VideoSwapPipeline.
+    validation): inversion with the AttentionStore -> ED-LoRA merge -> edit controller -> guided sampling with adapter
+    residuals for steps 0..25 and the blend callbacks -> weights restored.  Everything is inside the timed region."""
+    pipe.unet.clear_step_caches()
+    cfg = dict(use_invertion_latents=True, use_blend=True, num_inference_steps=ddim_steps, guidance_scale=7.5,
+               t2i_guidance_scale=0.5, t2i_start=0.0, t2i_end=0.5,
+               editing_prompts={'0': dict(replace='silver jeep -> <porsche1> <porsche2>',
+                                          lora_path='synthetic_edlora.pth---1.0',
+                                          blend_cfg=dict(cross_replace_steps=0.3, self_replace_steps=0.3, blend_th=0.3))})
+    video = data['latents'][0].permute(1, 0, 2, 3).contiguous()          # [F,4,h,w]: 4 channels = already latents
+    if marks is not None:
+        invert = pipe.invert
+
+        def marked(*a, **k):
+            r = invert(*a, **k)
+            marks.append(_event())
+            return r
+        pipe.invert = marked
+    try:
+        return pipe.validation(video, data['conditions'], SWAP_SOURCE, cfg, lora_loader=lambda path: lora)['0']
+    finally:
+        if marks is not None:
+            pipe.invert = invert
+
+
+def _event():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def one_clip(pipe, data, ddim_steps, marks=None):
     """The hot path for one clip: inversion (B=1) then guided sampling (B=2).  Every clip starts with cold
-    step-invariant caches (time-embedding rows, text K/V): nothing computed for one clip is reused by the next."""
+    step-invariant caches (time-embedding rows, text K/V): nothing computed for one clip is reused by the next.
+    `marks` receives a device event between the two loops (R1s = the sampling half alone; no host sync)."""
     pipe.unet.clear_step_caches()
     inv = pipe.invert(latents=data['latents'], prompt_embeds=data['text'], num_inference_steps=ddim_steps).latents
+    if marks is not None:
+        marks.append(_event())
     embeds = torch.cat([data['negative'], data['text']])
     out = pipe(prompt=None, conditions=None, prompt_embeds=embeds[1:], negative_prompt_embeds=embeds[:1],
                latents=inv, num_inference_steps=ddim_steps, guidance_scale=7.5, output_type='latent').videos
     return out
 
 
-def cpu_baseline(frames_sample=2, latent=64, repeats=2):
-    """The oracle (CPU port of the reference's PyTorch path, fp32) on the host cores: one inversion-step UNet forward
-    (B=1) on a bounded sample of `frames_sample` frames at the full SD-1.5 width and the same 64x64 latent; one
-    warm-up forward, then the median of `repeats` timed forwards (with the sample bounded to ~30 s of
-    CPU work as the bench contract asks: a full T=16 step pair is ~5 min on 128 cores)."""
+def cpu_baseline(frames_sample=2, latent=64):
+    """The oracle (CPU port of the reference's PyTorch path, fp32) on the host cores, on a bounded sample of what one
+    DDIM step pair costs (1 inversion step = a B=1 UNet forward, 1 CFG step = a B=2 forward): both
+    forwards at the full SD-1.5 width and the same 64x64 latent with T = `frames_sample` frames (a full T=16 step pair is
+    ~5 min on 128 cores; the bench contract asks for ~10-30 s).  One warm-up forward (B=1), then each forward once.
+    -> UNet frame-evaluations per second over the pair (3 * T evals)."""
     from oracle import unet3d
     torch.manual_seed(0)
     # PyTorch's default intra-op thread count (= physical cores).  Forcing os.cpu_count() (the SMT thread count) made
@@ -92,19 +165,53 @@ def cpu_baseline(frames_sample=2, latent=64, repeats=2):
     for n, p in model.named_parameters():           # proj_out is zero-initialised: make the temporal path live
         if 'temporal_transformer.proj_out' in n:
             torch.nn.init.normal_(p, std=0.02)
-    x = torch.randn(1, 4, frames_sample, latent, latent)
-    txt = torch.randn(1, 77, 768)
+    txt = torch.randn(2, 77, 768)
+    times = {}
+    with torch.no_grad():
+        x1 = torch.randn(1, 4, frames_sample, latent, latent)
+        model(x1, torch.tensor(481), txt[:1])       # warm-up (allocator, thread pool, oneDNN primitive caches)
+        for b in (1, 2):
+            x = torch.randn(b, 4, frames_sample, latent, latent)
+            t0 = time.time()
+            model(x, torch.tensor(481), txt[:b])
+            times[b] = time.time() - t0
+    evals_per_s = 3 * frames_sample / (times[1] + times[2])
+    return evals_per_s, threads, (f'1 inversion step (UNet B=1) + 1 CFG step (UNet B=2) at T={frames_sample}, '
+                                  f'{latent}x{latent} latent, fp32, after 1 warm-up forward: {times[1]:.1f} s + {times[2]:.1f} s')
+
+
+def torch_rocm_baseline(device, frames=16, latent=64, repeats=2):
+    """Second stated baseline: the SAME oracle module (plain PyTorch, the reference's GPU-style path: fp16 weights,
+    torch-ROCm eager ops = rocBLAS / MIOpen / SDPA) on this GPU — 1 inversion step (B=1) + 1 CFG step (B=2) at the full
+    T and latent, warm-up + median, extrapolated to the 50 + 50 steps (every step is identical work).  Runs AFTER the
+    timed region; never on the product path."""
+    from oracle import unet3d
+    with torch.device(device):
+        model = unet3d.AnimateDiffUNet3DModel(**unet3d.full_config()).eval()
+    for n, p in model.named_parameters():
+        if 'temporal_transformer.proj_out' in n:
+            torch.nn.init.normal_(p, std=0.02)
+    model = model.half()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, frames, latent, latent, generator=g).to(device, torch.float16)
+    txt = torch.randn(2, 77, 768, generator=g).to(device, torch.float16)
+
+    def pair():
+        model(x[:1], torch.tensor(481), txt[:1])
+        model(x, torch.tensor(481), txt)
     times = []
     with torch.no_grad():
-        model(x, torch.tensor(481), txt)            # warm-up (allocator, thread pool, oneDNN primitive caches)
+        pair()
+        torch.cuda.synchronize()
         for _ in range(repeats):
-            t0 = time.time()
-            model(x, torch.tensor(481), txt)
-            times.append(time.time() - t0)
+            t0 = time.perf_counter()
+            pair()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    evals_per_s = frames_sample / dt
-    return evals_per_s, threads, (f'1 UNet forward (inversion step), B=1, T={frames_sample}, {latent}x{latent} latent, '
-                                  f'fp32, 1 warm-up + median of {repeats}: {dt:.1f} s')
+    del model
+    torch.cuda.empty_cache()
+    return dt
 
 
 def gemm_traffic(frames, latent):
@@ -137,11 +244,20 @@ def main():
         dist.init_process_group('nccl', device_id=device)
 
     from videoswap_amd import ops
+    from videoswap_amd.distributed import max_over_ranks as max_over
     from videoswap_amd.synthetic import synthetic_clip
-    pipe = build_pipeline(device, args.frames)
+    swap = args.config == 3
+    lh, lw = args.latent_h or args.latent, args.latent_w or args.latent
+    pipe = build_pipeline(device, args.frames, swap=swap)
     # every rank owns different clips (seeded by rank); inputs resident in HBM before the timed region
-    clips = [synthetic_clip(seed=1000 * rank + i, frames=args.frames, height=args.latent, width=args.latent,
+    clips = [synthetic_clip(seed=1000 * rank + i, frames=args.frames, height=lh, width=lw,
                             device=device) for i in range(max(args.steps, 1))]
+    marks = []
+    if swap:
+        lora = synthetic_edlora(pipe.unet.state_dict())
+        run_clip = lambda data, steps, m=None: swap_clip(pipe, data, steps, lora, m)      # noqa: E731
+    else:
+        run_clip = lambda data, steps, m=None: one_clip(pipe, data, steps, m)             # noqa: E731
 
     def barrier():
         if distributed:
@@ -154,9 +270,9 @@ def main():
         # are bracketed by hipEvents (ALL of them: same 1/stride sampling fraction as the eager mode's every-7th-launch)
         pipe.unet.enable_hip_graphs(True, eager_every=args.prof_stride if args.prof_samples > 0 else 0)
         if args.warmup == 0:
-            one_clip(pipe, clips[0], 1)              # capture the two graphs (B=1, B=2) outside the timed region
+            run_clip(clips[0], 1)                    # capture the two graphs (B=1, B=2) outside the timed region
     for i in range(args.warmup):
-        one_clip(pipe, clips[i % len(clips)], args.ddim_steps)
+        run_clip(clips[i % len(clips)], args.ddim_steps)
     barrier()
     if graphs:
         pipe.unet._graphs.on_eager = (lambda on: ops.prof_pause(not on))
@@ -167,16 +283,23 @@ def main():
         ops.prof_pause(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_clip(pipe, clips[i % len(clips)], args.ddim_steps)
+        marks.append(_event())                       # clip start | (inside the clip) end of the inversion | clip end
+        run_clip(clips[i % len(clips)], args.ddim_steps, marks)
+        marks.append(_event())
     barrier()
     elapsed = time.perf_counter() - t0
+    # device time of the two halves of every clip (events on the launch stream; nothing was synchronised in between)
+    inv_s = sum(marks[3 * i].elapsed_time(marks[3 * i + 1]) for i in range(args.steps)) * 1e-3
+    smp_s = sum(marks[3 * i + 1].elapsed_time(marks[3 * i + 2]) for i in range(args.steps)) * 1e-3
+    if distributed:
+        smp_s = max_over(smp_s, device)
+        inv_s = max_over(inv_s, device)
     ops.FlopCounter.enabled = False
     ops.prof_pause(False)
     n_launch, gemm_ms, gemm_flop = ops.prof_collect()
     ops.prof_enable(False, 0)
 
-    from videoswap_amd.distributed import max_over_ranks
-    elapsed = max_over_ranks(elapsed, device)        # whole-job time = slowest rank
+    elapsed = max_over(elapsed, device)              # whole-job time = slowest rank
 
     frames_total = world * args.steps * args.frames
     value = frames_total / elapsed
@@ -187,11 +310,20 @@ def main():
         'value': round(value, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 2), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-        'config': {'launch': 'hip-graph' if graphs else 'eager', 'workload': f'{args.frames}-frame {args.latent * 8}x{args.latent * 8} clip, SD-1.5 UNet3D + '
-                               f'AnimateDiff motion modules, {args.ddim_steps}-step DDIM inversion (B=1) + '
-                               f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B=2), one clip per GPU per step',
-                   'latents': [1, 4, args.frames, args.latent, args.latent], 'parallelism': f'clip-parallel x{world}'},
+        'config': {'launch': 'hip-graph' if graphs else 'eager',
+                   'workload': (f'BASELINE.json configs[{args.config - 1}]: {args.frames}-frame {lw * 8}x{lh * 8} clip, SD-1.5 UNet3D + '
+                                f'AnimateDiff motion modules, {args.ddim_steps}-step DDIM inversion (B=1) + '
+                                f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B=2), one clip per GPU per step'
+                                + ('; full swap path (VideoSwapPipeline.validation): AttentionStore during the inversion, '
+                                   'ED-LoRA merge + per-layer text embeddings [2,16,77,768], point-adapter residuals for '
+                                   'sampling steps 0-25, AttentionRefine + latent / self-attention SpatialBlenders '
+                                   '(use_blend), weights restored' if swap else '')),
+                   'latents': [1, 4, args.frames, lh, lw], 'parallelism': f'clip-parallel x{world}'},
         'readings': {'R1e_frames_per_s': round(value, 4),
+                     # R1s: the guided-sampling half alone (frames / device time of the 50 CFG steps)
+                     'R1s_frames_per_s': round(frames_total / world / smp_s * world, 4) if smp_s > 0 else None,
+                     'inversion_s_per_clip': round(inv_s / max(args.steps, 1), 4),
+                     'sampling_s_per_clip': round(smp_s / max(args.steps, 1), 4),
                      'R2_unet_frame_evals_per_s': round(evals / elapsed, 2),
                      'loop_algorithmic_tflop': round(total_flop / 1e12, 1),
                      'loop_tflops': round(total_flop / elapsed / 1e12, 1),
@@ -200,7 +332,7 @@ def main():
     }
     if n_launch > 0 and gemm_ms > 0:
         ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-        traffic, traffic_note = gemm_traffic(args.frames, args.latent)
+        traffic, traffic_note = gemm_traffic(args.frames, args.latent if (lh == lw == args.latent and not swap) else -1)
         out['roofline'] = {'bound': 'mfma', 'kernel': 'vsx_gemm_f16 (implicit-GEMM conv + GEMM, all shapes)',
                            'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_note,
@@ -220,6 +352,17 @@ def main():
         except Exception as e:  # the baseline must never take the GPU number down with it
             out['cpu_baseline'] = {'value': None, 'unit': 'frames/s', 'cores': torch.get_num_threads(),
                                    'kind': 'port', 'sample': f'failed: {e!r}'}
+        try:
+            del pipe, clips
+            torch.cuda.empty_cache()
+            pair_s = torch_rocm_baseline(device, args.frames, lh if lh == lw else args.latent)
+            out['torch_rocm_eager_fp16'] = {
+                'value': round(args.frames / (args.ddim_steps * pair_s), 4), 'unit': 'frames/s',
+                'sample': f'oracle module (plain PyTorch-ROCm eager, fp16) on the same GPU: 1 inversion step (B=1) + 1 CFG '
+                          f'step (B=2) at T={args.frames}, median of 2 after warm-up = {pair_s * 1e3:.0f} ms, x {args.ddim_steps} steps',
+                'speedup_of_value': round(value * args.ddim_steps * pair_s / args.frames, 2)}
+        except Exception as e:
+            out['torch_rocm_eager_fp16'] = {'value': None, 'unit': 'frames/s', 'sample': f'failed: {e!r}'}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:

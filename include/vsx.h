@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 4
+#define VSX_ABI_VERSION 5
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -236,7 +236,16 @@ int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* total_flop);
  *       vsx_temporal_attention_f16 reads with fk = F_total (K = columns [0,C), V = [C,2C), ldkv = 2C);
  *   vsx_allgather_f32: fp32 GroupNorm partial sums (vsx_groupnorm_stats) of every rank, rank order;
  *       vsx_groupnorm_apply then reduces them in a fixed order: identical statistics on every rank;
- *   vsx_allreduce_gnstats: in-place fp32 sum over the ranks.
+ *   vsx_allreduce_gnstats: in-place fp32 sum over the ranks;
+ *   vsx_alltoall_f16: the frames <-> sites re-shard of FrameShard(exchange='sites') (everything between a motion
+ *       module's proj_in and proj_out is local to a SITE, motion_module.py:138-162,222-234) as ONE group of
+ *       ncclSend / ncclRecv straight from / into the strided activation layouts (no pack / unpack passes): for every
+ *       peer p and block (o, i), o < nouter, i < ninner, `block_elems` contiguous fp16 elements travel from
+ *           send + p*send_strides[0] + o*send_strides[1] + i*send_strides[2]   on this rank   to
+ *           recv + r*recv_strides[0] + o*recv_strides[1] + i*recv_strides[2]   on rank p   (r = this rank; strides in
+ *       elements).  frames -> sites ([B, f, P, hw/P, C] -> [B, P, f, hw/P, C]): nouter = B, ninner = f,
+ *       block = hw/P*C, send strides (block, f*P*block, P*block), recv strides (f*block, P*f*block, block);
+ *       sites -> frames is the same call with the two stride triples exchanged.
  * ------------------------------------------------------------------------------------------ */
 int vsx_comm_unique_id(void* id128);
 int vsx_comm_init(int64_t rank, int64_t nranks, const void* id128);
@@ -247,6 +256,40 @@ int vsx_allgather_kv(const void* kv_local, void* kv_all, int64_t batch, int64_t 
                      vsx_stream_t stream);
 int vsx_allgather_f32(const float* local, float* all, int64_t count, vsx_stream_t stream);
 int vsx_allreduce_gnstats(float* partial, int64_t count, vsx_stream_t stream);
+int vsx_alltoall_f16(const void* send, void* recv, int64_t nouter, int64_t ninner, int64_t block_elems,
+                     const int64_t* send_strides, const int64_t* recv_strides, vsx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gradient path of the adapter training step (trainer_videoswap.py:33-97 —
+ * `accelerator.backward(loss)` through the frozen UNet into the SparsePointAdapter, adapter_model.py:70-107).
+ * Only DATA gradients are needed (the UNet's weights are frozen); the matrix work of the backward pass (linear /
+ * conv dgrad, attention products, the adapter MLP's weight gradients) runs on vsx_gemm_f16 with transposed /
+ * flipped operands (videoswap_amd/autograd.py).  These are the element-wise / reduction passes: fp16 tensors,
+ * fp32 arithmetic, fixed-order reductions (no atomics: deterministic).
+ *   vsx_geglu_fwd     y2 [M, 2N] (h | g pre-activations, kept for the backward) -> out [M, N] = h * gelu_erf(g)
+ *                     (diffusers GEGLU as its own pass; inference fuses it into the GEMM epilogue and drops y2)
+ *   vsx_geglu_bwd     dout [M, N], y2 [M, 2N] -> dy2 [M, 2N]
+ *   vsx_silu_bwd      dx = dy * silu'(x)   (adapter MLP, adapter_model.py:12-22)
+ *   vsx_groupnorm_bwd data gradient of vsx_groupnorm_apply (same arguments; statistics recomputed; dy [.., C1+C2]
+ *                     -> dx1 [.., C1], dx2 [.., C2]); ws: nimg*groups*4 floats   (resnet.py:166-177)
+ *   vsx_layernorm_bwd data gradient of vsx_layernorm (the positional encoding is added after the normalisation)
+ *   vsx_softmax_bwd   dS = scale * P o (dP - rowsum(dP o P)) in place over dP, rows padded to ld
+ *   vsx_sum_pool2x2   [n, 2h, 2w, c] -> [n, h, w, c]: gradient of the nearest-2x upsampling folded into a conv
+ *   vsx_adapter_gather gradient of vsx_adapter_scatter with respect to feat [P, C] (adapter_model.py:25-47)
+ * ------------------------------------------------------------------------------------------ */
+int vsx_geglu_fwd(const void* y2, void* out, int64_t M, int64_t N, vsx_stream_t stream);
+int vsx_geglu_bwd(const void* dout, const void* y2, void* dy2, int64_t M, int64_t N, vsx_stream_t stream);
+int vsx_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, vsx_stream_t stream);
+int vsx_groupnorm_bwd(const void* dy, const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
+                      int64_t C2, int64_t groups, const void* gamma, const void* beta, float eps, int64_t silu,
+                      void* ws, void* dx1, void* dx2, vsx_stream_t stream);
+int vsx_layernorm_bwd(const void* dy, const void* x, const void* gamma, float eps, void* dx, int64_t M, int64_t C,
+                      vsx_stream_t stream);
+int vsx_softmax_bwd(const void* P, void* dP, int64_t nrows, int64_t ncols, int64_t ld, float scale,
+                    vsx_stream_t stream);
+int vsx_sum_pool2x2(const void* x, void* y, int64_t n, int64_t h, int64_t w, int64_t c, vsx_stream_t stream);
+int vsx_adapter_gather(const float* tracks, const int32_t* selected, const void* dmap, void* dfeat, int64_t F,
+                       int64_t P, int64_t C, int64_t h, int64_t w, float rate, float out_scale, vsx_stream_t stream);
 
 #ifdef __cplusplus
 }

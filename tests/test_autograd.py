@@ -4,7 +4,7 @@ d loss / d adapter residuals against the oracle's autograd.
 
 `device` tests: on CPU they run on tests/host_emulation.py (the backward passes are built from kernel functions, so
 what is checked here is the composition: transposed / flipped weights, zero insertion, re-materialised attention, layout
-round trips); on a GPU box they need the development library that carries the backward kernels (VSX_LIB_VARIANT=next)."""
+round trips); on a GPU box the backward kernels of libvsx.so (csrc/train.hip) run."""
 import os
 
 import pytest
@@ -13,9 +13,7 @@ import torch.nn.functional as F
 
 from util import DEV, oracle_unet, product_unet_from, rel_l2
 
-pytestmark = [pytest.mark.device,
-              pytest.mark.skipif(DEV == 'cuda' and os.environ.get('VSX_LIB_VARIANT') != 'next',
-                                 reason='the backward kernels are in the development library (VSX_LIB_VARIANT=next)')]
+pytestmark = pytest.mark.device
 H = torch.float16
 
 

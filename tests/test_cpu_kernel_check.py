@@ -1,11 +1,11 @@
 """Kernels executed FROM THEIR SOURCE on the CPU (tools/cpu_check): the backward kernels of the training step and the
 development library's persistent MFMA GEMM / conv kernel with its candidate piece schedules.
 
-The backward kernels of the training step (videoswap_amd/csrc/experimental/train.hip) executed FROM THEIR SOURCE on the
+The backward kernels of the training step (videoswap_amd/csrc/train.hip) executed FROM THEIR SOURCE on the
 CPU: tools/cpu_check/hip/hip_runtime.h maps the HIP execution model of these simple kernels (a workgroup = OS threads,
 __syncthreads = a barrier, __shfl_xor = an exchange between two wave barriers) onto the host, tools/cpu_check/check_train.cpp
 calls every C-ABI entry point and compares with a double-precision restatement of the formula.  This checks index
-arithmetic and reduction logic without a GPU; the GPU tests (tests/test_autograd.py, VSX_LIB_VARIANT=next) remain the
+arithmetic and reduction logic without a GPU; the GPU tests (tests/test_autograd.py) remain the
 parity tests proper."""
 import os
 import shutil

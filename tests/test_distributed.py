@@ -153,7 +153,7 @@ def test_site_reshard_exchange(world):
 
 
 def _simulate_alltoall(sends, nouter, ninner, block, send_strides, recv_strides, out_numel):
-    """vsx_alltoall_f16's contract (csrc/experimental/comm.cpp) for all ranks in one process: block (o, i) for peer p
+    """vsx_alltoall_f16's contract (csrc/comm.cpp) for all ranks in one process: block (o, i) for peer p
     leaves rank r at p*ss[0] + o*ss[1] + i*ss[2] and lands on rank p at r*rs[0] + o*rs[1] + i*rs[2]."""
     world = len(sends)
     outs = [torch.full((out_numel,), float('nan')) for _ in range(world)]

@@ -109,10 +109,7 @@ def _worker_full(rank, world, port, q, exchange='kv'):
         q.put(('error', rank, traceback.format_exc()))
 
 
-SITES = pytest.param('sites', marks=pytest.mark.skipif(
-    os.environ.get('VSX_TEST_SITES') != '1',
-    reason="exchange='sites' is covered by the world-2/4 gloo tests on CPU; its single-GPU emulation has not run on "
-           "hardware yet (set VSX_TEST_SITES=1)"))
+SITES = 'sites'      # green on an MI355X since round 3 (gpurun_out r03a): runs by default
 
 
 def _spawn(worker, world=2, timeout=600, exchange='kv'):
@@ -176,8 +173,6 @@ def test_frame_sharded_unet_matches_full_clip_oracle(exchange):
     assert uncoupled > 3 * err
 
 
-@pytest.mark.skipif(os.environ.get('VSX_LIB_VARIANT') != 'next',
-                    reason='vsx_alltoall_f16 is exported by the development library only (VSX_LIB_VARIANT=next)')
 def test_alltoall_entry_point_single_rank():
     """vsx_alltoall_f16 with a one-rank communicator: the strided self-block copy must reproduce the re-shard layouts
     (the multi-rank stride arithmetic is checked on CPU: tests/test_distributed.py::test_strided_alltoall_layouts...)."""

@@ -41,7 +41,9 @@ def _shard_worker(rank, world, port, q, exchange):
         import host_emulation as he
         from oracle import unet3d
         from videoswap_amd.distributed import FrameShard
-        T, HW = 8, 16
+        # 'auto' on a 24x24 latent: levels of 576 / 144 / 36 / 9 sites — the 3x3 level does not split over 2 ranks and
+        # falls back to the K|V all-gather, the others take the site re-shard
+        T, HW = 8, (24 if exchange == 'auto' else 16)
         cfg = unet3d.tiny_config()
         ora = oracle_unet(cfg)
         prod = product_unet_from(ora, cfg, device='cpu')
@@ -68,7 +70,7 @@ def _shard_worker(rank, world, port, q, exchange):
         q.put(('error', rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize('exchange', ['kv', 'sites'])
+@pytest.mark.parametrize('exchange', ['kv', 'sites', 'auto'])
 def test_frame_sharded_unet_host_mirror(exchange):
     """The real UNet, two ranks of 4 frames each (gloo): gathered output = full-clip oracle, and equal (to fp16 rounding
     noise) to the unsharded product on the full clip; without the exchange the half clip differs visibly."""

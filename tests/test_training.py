@@ -2,7 +2,7 @@
 verbatim (same python RNG: same dropped points, same loss mask, same maps); the product's `VideoSwapTrainer` pieces
 against the oracle restatement of trainer_videoswap.py:57-93 — loss value and the gradient of every adapter parameter
 (HIP forward + backward through the frozen UNet vs PyTorch autograd on the fp32 oracle) — and one full optimizer
-step.  `device` tests need the development library on a GPU box (the backward kernels: VSX_LIB_VARIANT=next)."""
+step.  `device` tests run the backward kernels of libvsx.so (csrc/train.hip) on a GPU box."""
 import copy
 import os
 import random
@@ -12,9 +12,7 @@ import torch
 
 from util import DEV, cosine, oracle_unet, product_unet_from, rel_l2
 
-NEEDS_BWD = [pytest.mark.device,
-             pytest.mark.skipif(DEV == 'cuda' and os.environ.get('VSX_LIB_VARIANT') != 'next',
-                                reason='the backward kernels are in the development library (VSX_LIB_VARIANT=next)')]
+NEEDS_BWD = [pytest.mark.device]
 TUNE = {'min_timestep': 0.5, 'drop_rate': 0.3, 'loss_type': 'local'}
 
 

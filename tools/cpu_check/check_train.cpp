@@ -1,4 +1,4 @@
-// Runs the backward kernels of videoswap_amd/csrc/experimental/train.hip on the CPU (hip/hip_runtime.h next to this file)
+// Runs the backward kernels of videoswap_amd/csrc/train.hip on the CPU (hip/hip_runtime.h next to this file)
 // and compares every output with a plain double-precision restatement of the same formula.
 //   make -C tools/cpu_check        (or: clang++ -std=c++20 -O1 -pthread -I tools/cpu_check -I include -I videoswap_amd/csrc ...)
 #include <stdio.h>
@@ -18,7 +18,7 @@ int vsx_fail(int code, const char* fmt, ...) {
 }
 int vsx_check_launch(const char*) { return 0; }
 
-#include "experimental/train.hip"
+#include "train.hip"
 
 static unsigned rng_state = 12345u;
 static float frand() {                      // uniform in [-1, 1)

@@ -22,12 +22,15 @@ constexpr int NM = 14;      // MFMAs per iteration (one 64-key tile of the d = 4
 constexpr int NEXP = 32;    // v_exp_f32 per iteration
 constexpr int NFMA = 64;    // other VALU ops per iteration (max3 / fma / cvt stand-ins)
 
-template <int MODE, int WAVES>   // 0 mfma, 1 valu, 2 same wave, 3 split by wave parity within a SIMD
+template <int MODE, int WAVES>   // 0 mfma, 1 valu, 2 same wave, 3 split by wave parity within a SIMD, 4 same wave interleaved
 __global__ __launch_bounds__(64 * WAVES) void probe(float* __restrict__ sink, long* __restrict__ cycles, int iters) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // readfirstlane: the wave index must be UNIFORM for the compiler, otherwise `if (do_mfma)` is a divergent branch and
+    // both sides execute under an EXEC mask (round-3 run 1 measured exactly that: `split` with 1 wave per SIMD, where
+    // every wave only does MFMAs, took as long as `same-wave`)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // waves w, w+4, w+8 ... share SIMD w % 4; "parity within the SIMD" = (wave / 4) & 1
-    const bool do_mfma = MODE == 0 || MODE == 2 || (MODE == 3 && ((wave >> 2) & 1) == 0);
-    const bool do_valu = MODE == 1 || MODE == 2 || (MODE == 3 && ((wave >> 2) & 1) == 1);
+    const bool do_mfma = MODE == 0 || MODE == 2 || MODE == 4 || (MODE == 3 && ((wave >> 2) & 1) == 0);
+    const bool do_valu = MODE == 1 || MODE == 2 || MODE == 4 || (MODE == 3 && ((wave >> 2) & 1) == 1);
     h8 a, b;
     for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.001f * (lane + e)); b[e] = (_Float16)(0.002f * (lane - e)); }
     f16v acc[4];
@@ -40,6 +43,15 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* __restrict__ sink, lo
         if (do_mfma) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m & 3], 0, 0, 0);
+        }
+        if (MODE == 4) {
+            // program order forced to 1 MFMA : 2 exp : 5 fma groups (the in-order wave can issue its VALU work while its
+            // own MFMA occupies the matrix pipe only if the instructions ALTERNATE in the instruction stream)
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            }
         }
         if (do_valu) {
 #pragma unroll
@@ -73,11 +85,12 @@ static void table(float* sink, long* cyc, int blocks, int iters) {
     // s_memtime counts a fixed-frequency clock: report ratios, which are what matters
     const double m = run<0, WAVES>(sink, cyc, blocks, iters), v = run<1, WAVES>(sink, cyc, blocks, iters);
     const double b = run<2, WAVES>(sink, cyc, blocks, iters), s = run<3, WAVES>(sink, cyc, blocks, iters);
+    const double il = run<4, WAVES>(sink, cyc, blocks, iters);
     // split does half of the `mfma` work and half of the `valu` work per SIMD: no overlap -> (mfma + valu) / 2,
     // perfect overlap across waves -> max(mfma, valu) / 2
     printf("%2d waves per CU (%d per SIMD): mfma %8.2f  valu %8.2f  same-wave %8.2f (%.2f x (mfma + valu))  "
-           "split %8.2f (no overlap would be %.2f, perfect overlap %.2f)\n", WAVES, WAVES / 4, m, v, b, b / (m + v), s,
-           (m + v) / 2, (m > v ? m : v) / 2);
+           "interleaved same-wave %8.2f  split %8.2f (no overlap would be %.2f, perfect overlap %.2f)\n", WAVES, WAVES / 4,
+           m, v, b, b / (m + v), il, s, WAVES >= 8 ? (m + v) / 2 : m, WAVES >= 8 ? (m > v ? m : v) / 2 : m);
 }
 
 int main() {

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.environ.get('VSX_LIB_VARIANT') or None
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so' if not VARIANT else f'libvsx_{VARIANT}.so')
 
-VSX_ABI_VERSION = 4
+VSX_ABI_VERSION = 5
 
 
 class VsxError(RuntimeError):
@@ -89,11 +89,7 @@ PROTOTYPES = {
     'vsx_allreduce_gnstats': (c_int, [c_void_p, c_int64, c_void_p]),
     'vsx_prof_pause': (c_int, [c_int64]),
     'vsx_prof_collect': (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
-}
-
-# entry points that only the development variant exports so far (typed when present)
-OPTIONAL_PROTOTYPES = {
-    # gradient path of the adapter training step (csrc/experimental/train.hip)
+    # gradient path of the adapter training step (csrc/train.hip)
     'vsx_geglu_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'vsx_geglu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'vsx_silu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -107,6 +103,9 @@ OPTIONAL_PROTOTYPES = {
     'vsx_alltoall_f16': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, POINTER(c_int64), POINTER(c_int64),
                                  c_void_p]),
 }
+
+# entry points that only a development variant exports (typed when present); none at the moment
+OPTIONAL_PROTOTYPES = {}
 
 _lib = None
 

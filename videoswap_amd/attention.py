@@ -264,7 +264,13 @@ class VanillaAttentionProcessor(nn.Module):
                                               max_len=temporal_position_encoding_max_len) \
             if temporal_position_encoding else None
         self.kv_gather = None      # set by videoswap_amd.distributed for frame sharding
-        self.frame_offset = 0
+
+    @property
+    def frame_offset(self):
+        """Global index of the first local frame (positional encoding) while the K|V all-gather form of frame sharding
+        is active; 0 otherwise (unsharded, or the block runs on the site layout where every frame is local)."""
+        g = self.kv_gather
+        return g.frame_offset if g is not None and g.kv_active else 0
 
     def pe_table(self):
         return None if self.pos_encoder is None else self.pos_encoder.table()
@@ -280,7 +286,7 @@ class VanillaAttentionProcessor(nn.Module):
             x = (x.view(b, frames, hw, c) + pe[None, :, None, :]).view(bf, hw, c)
         nobias = attn.to_q.bias is None and attn.to_k.bias is None and attn.to_v.bias is None
         fk = frames
-        if self.kv_gather is not None:
+        if self.kv_gather is not None and self.kv_gather.kv_active:
             # frame-sharded long clip: K|V of the local frames first (one GEMM, N = 2C), their all-gather over the
             # frame axis goes in flight, the q projection runs behind it
             if nobias:

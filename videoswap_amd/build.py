@@ -23,10 +23,10 @@ LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIB = os.path.join(LIBDIR, 'libvsx.so')
 # variant name -> {source file of SOURCES: replacement, relative to csrc/}
-VARIANTS = {'next': {'gemm_pp.hip': 'experimental/gemm_pp.hip', 'comm.cpp': 'experimental/comm.cpp'}}
+VARIANTS = {'next': {'gemm_pp.hip': 'experimental/gemm_pp.hip'}}
 # variant name -> additional sources (relative to csrc/)
-VARIANT_EXTRA = {'next': ['experimental/train.hip']}
-SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip']
+VARIANT_EXTRA = {}
+SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'train.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-Wall', '-Wno-unused-function', '-Wno-division-by-zero',

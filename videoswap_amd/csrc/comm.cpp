@@ -28,6 +28,8 @@ struct Rccl {
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -53,6 +55,8 @@ int open_rccl() {
     VSX_SYM(CommDestroy, "ncclCommDestroy");
     VSX_SYM(AllGather, "ncclAllGather");
     VSX_SYM(AllReduce, "ncclAllReduce");
+    VSX_SYM(Send, "ncclSend");
+    VSX_SYM(Recv, "ncclRecv");
     VSX_SYM(GroupStart, "ncclGroupStart");
     VSX_SYM(GroupEnd, "ncclGroupEnd");
     VSX_SYM(GetErrorString, "ncclGetErrorString");
@@ -132,4 +136,45 @@ extern "C" int vsx_allreduce_gnstats(float* partial, int64_t count, vsx_stream_t
     VSX_REQUIRE(partial && count > 0, VSX_E_BADSHAPE, "allreduce_gnstats: bad arguments");
     return check(g.AllReduce(partial, partial, (size_t)count, ncclFloat32, ncclSum, g.comm, (hipStream_t)stream),
                  "ncclAllReduce");
+}
+
+/* All-to-all of fp16 blocks with two-level strides (elements) on both sides: for every peer p and block (o, i),
+ * o < nouter, i < ninner, `block_elems` contiguous elements travel from
+ *     send + p * send_strides[0] + o * send_strides[1] + i * send_strides[2]     on this rank   to
+ *     recv + r * recv_strides[0] + o * recv_strides[1] + i * recv_strides[2]     on rank p      (r = this rank).
+ * frames -> sites ([B, f, P, hw/P, C] -> [B, P, f, hw/P, C]): nouter = B, ninner = f, block = hw/P * C,
+ *     send strides (block, f*P*block, P*block), recv strides (f*block, P*f*block, block); sites -> frames is the
+ *     same call with the two stride triples exchanged.  One group = one RCCL launch; the block to this rank itself is
+ *     a device copy on the same stream. */
+extern "C" int vsx_alltoall_f16(const void* send, void* recv, int64_t nouter, int64_t ninner, int64_t block_elems,
+                                const int64_t* send_strides, const int64_t* recv_strides, vsx_stream_t stream) {
+    VSX_REQUIRE(g.comm != nullptr, VSX_E_UNSUPPORTED, "alltoall_f16: no communicator (vsx_comm_init)");
+    VSX_REQUIRE(send && recv && send_strides && recv_strides && nouter > 0 && ninner > 0 && block_elems > 0,
+                VSX_E_BADSHAPE, "alltoall_f16: bad arguments");
+    const half_t* src = static_cast<const half_t*>(send);
+    half_t* dst = static_cast<half_t*>(recv);
+    for (int64_t o = 0; o < nouter; ++o)
+        for (int64_t i = 0; i < ninner; ++i) {
+            const hipError_t e = hipMemcpyAsync(
+                dst + g.rank * recv_strides[0] + o * recv_strides[1] + i * recv_strides[2],
+                src + g.rank * send_strides[0] + o * send_strides[1] + i * send_strides[2],
+                (size_t)block_elems * sizeof(half_t), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+            if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "alltoall_f16: local copy: %s", hipGetErrorString(e));
+        }
+    if (g.nranks == 1) return VSX_OK;
+    int rc = check(g.GroupStart(), "ncclGroupStart");
+    if (rc) return rc;
+    for (int p = 0; p < g.nranks && !rc; ++p) {
+        if (p == g.rank) continue;
+        for (int64_t o = 0; o < nouter && !rc; ++o)
+            for (int64_t i = 0; i < ninner && !rc; ++i) {
+                rc = check(g.Send(src + p * send_strides[0] + o * send_strides[1] + i * send_strides[2],
+                                  (size_t)block_elems, ncclFloat16, p, g.comm, (hipStream_t)stream), "ncclSend");
+                if (!rc)
+                    rc = check(g.Recv(dst + p * recv_strides[0] + o * recv_strides[1] + i * recv_strides[2],
+                                      (size_t)block_elems, ncclFloat16, p, g.comm, (hipStream_t)stream), "ncclRecv");
+            }
+    }
+    const int rc_end = check(g.GroupEnd(), "ncclGroupEnd");
+    return rc ? rc : rc_end;
 }

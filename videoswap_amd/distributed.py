@@ -103,15 +103,19 @@ class FrameShard:
     emulation).  Either way each exchange is ONE collective per batch item into a preallocated buffer laid out as the
     attention kernel reads it ([B, F_total, hw, 2C]: K = columns [0, C), V = [C, 2C)).
 
-    `exchange='kv'` (default, the form that has run on hardware) gathers the temporal K|V; `exchange='sites'` re-shards
-    the activation frames <-> sites around every motion module instead (module docstring): `to_sites` / `to_frames`,
-    one all-to-all each (torch.distributed, or the library's vsx_alltoall_f16 once it exports it)."""
+    `exchange='kv'` gathers the temporal K|V; `exchange='sites'` re-shards the activation frames <-> sites around every
+    motion module instead (module docstring): `to_sites` / `to_frames`, one all-to-all each (torch.distributed, or the
+    library's vsx_alltoall_f16 with backend 'rccl').  The default `'auto'` decides per motion module: the site re-shard
+    (4x fewer bytes at 2 ranks, 16x at 8; both forms measured on an MI355X in round 3: same rel-L2 against the full-clip
+    oracle, 190 vs 760 MB received per rank and forward at 2 x 32 frames) wherever the level's site count splits over
+    the ranks, the K|V all-gather where it does not (e.g. the 7 x 12 level of a 448 x 768 clip on 8 ranks)."""
 
-    def __init__(self, total_frames, group=None, backend=None, exchange='kv'):
-        if exchange not in ('kv', 'sites'):
-            raise ValueError("exchange must be 'kv' (all-gather of the temporal K|V) or 'sites' (frame <-> site "
+    def __init__(self, total_frames, group=None, backend=None, exchange='auto'):
+        if exchange not in ('auto', 'kv', 'sites'):
+            raise ValueError("exchange must be 'auto', 'kv' (all-gather of the temporal K|V) or 'sites' (frame <-> site "
                              "all-to-all around every motion module)")
         self.exchange = exchange
+        self.kv_active = True                    # switched off while a motion module runs on the site layout
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -181,6 +185,15 @@ class FrameShard:
         return out.view(-1, c2), self.total_frames
 
     # ---- frames <-> sites (exchange = 'sites') ---------------------------------------------------------------------
+    def use_sites(self, hw):
+        """Does the motion module at a level with `hw` sites run on the site layout?"""
+        if self.exchange == 'kv':
+            return False
+        if self.exchange == 'sites':
+            self.sites_per_rank(hw)              # raises when the level does not split
+            return True
+        return hw % self.world == 0
+
     def sites_per_rank(self, hw):
         if hw % self.world:
             raise ValueError(f"exchange='sites' needs every level's site count to split over the ranks: {hw} sites, "
@@ -189,7 +202,7 @@ class FrameShard:
 
     def _alltoall_strided(self, src, dst, b, block, send_strides, recv_strides):
         """RCCL path of both re-shards through the C ABI (vsx_alltoall_f16: grouped send / recv straight from / into the
-        strided layouts, no pack / unpack passes).  Only the development library exports it so far."""
+        strided layouts, no pack / unpack passes)."""
         import ctypes
         from . import _lib, ops
         arr = ctypes.c_int64 * 3
@@ -253,9 +266,8 @@ class FrameShard:
         for m in unet.modules():
             proc = getattr(m, 'processor', None)
             if isinstance(proc, VanillaAttentionProcessor):
-                if self.exchange == 'kv':        # 'sites': the temporal transformer sees every frame, no hook needed
-                    proc.kv_gather = self
-                    proc.frame_offset = self.frame_offset
+                if self.exchange != 'sites':     # 'sites': the temporal transformer sees every frame, no hook needed
+                    proc.kv_gather = self        # ('auto': consulted only while `kv_active`)
                 if proc.pos_encoder is not None and proc.pos_encoder.pe.shape[1] < self.total_frames:
                     raise ValueError('temporal_position_encoding_max_len is smaller than the clip: build the UNet with '
                                      f'max_len >= {self.total_frames}')
@@ -269,7 +281,6 @@ class FrameShard:
             proc = getattr(m, 'processor', None)
             if isinstance(proc, VanillaAttentionProcessor):
                 proc.kv_gather = None
-                proc.frame_offset = 0
 
     def local_slice(self, latents):
         """[B, C, F, H, W] -> this rank's frames"""

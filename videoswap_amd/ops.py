@@ -500,15 +500,11 @@ def prof_collect():
 
 
 # --------------------------------------------------------------------------------------------
-# kernel functions of the gradient path (adapter training step).  Their kernels live in the development
-# library (csrc/experimental/train.hip, VSX_LIB_VARIANT=next) until they have been verified on hardware.
+# kernel functions of the gradient path (adapter training step): csrc/train.hip, declared in
+# include/vsx.h since ABI 5 (first run on hardware in round 3)
 # --------------------------------------------------------------------------------------------
 def _train_fn(name):
-    fn = getattr(_lib.load(), name, None)
-    if fn is None:
-        raise _lib.VsxError(f'{name}: the training kernels are part of the development library only '
-                            f'(python -m videoswap_amd.build --variant next; VSX_LIB_VARIANT=next)')
-    return fn
+    return getattr(_lib.load(), name)
 
 
 def geglu_fwd(y2):

@@ -121,3 +121,53 @@ def synth_weights_(model, seed=1234):
         if 'temporal_transformer.proj_out' in name:
             p.copy_((torch.randn(p.shape, generator=g, device=dev) * 0.02).to(p.dtype))
     return model
+
+
+def _hash_uniform(n, key, device):
+    """n uniform numbers in [0, 1) from a 32-bit integer hash of (index, key): integer arithmetic and one exact
+    int -> float conversion only, so the CPU and a GPU produce the SAME bits (torch.Generator streams differ per device)."""
+    m = 0xFFFFFFFF
+    h = (torch.arange(n, dtype=torch.int64, device=device) * 2654435761 + (int(key) & m)) & m
+    for _ in range(2):
+        h = h ^ (h >> 16)
+        h = (h * 0x45D9F3B) & m
+    h = h ^ (h >> 16)
+    return (h >> 8).to(torch.float32) * (1.0 / (1 << 24))
+
+
+@torch.no_grad()
+def portable_weights_(model, seed=1234):
+    """The same recipe as `synth_weights_` with device-independent numbers: a golden vector recorded on the build
+    container's CPU (tests/golden/make_golden_cfg3.py) and the model on the GPU box get bit-identical parameters.
+    Normal draws are the sum of four uniforms (Irwin-Hall, variance 1/3), which is all a synthetic weight needs."""
+    dev = next(model.parameters()).device
+
+    def uni(p, key):
+        return _hash_uniform(p.numel(), key, dev).view(p.shape)
+
+    def nrm(p, key):
+        u = uni(p, key) + uni(p, key + 1) + uni(p, key + 2) + uni(p, key + 3)
+        return (u - 2.0) * 1.7320508
+    for name, p in model.named_parameters():
+        key = seed * 1000003 + int(hashlib.sha1(name.encode()).hexdigest()[:7], 16)
+        if 'temporal_transformer.proj_out' in name:
+            v = nrm(p, key) * 0.02
+        elif p.dim() > 1:
+            v = (uni(p, key) * 2 - 1) * (1.0 / (p[0].numel() ** 0.5))
+        elif 'norm' in name and name.endswith('weight'):
+            v = uni(p, key) + 0.5
+        elif 'norm' in name and name.endswith('bias'):
+            v = nrm(p, key) * 0.1
+        else:
+            v = (uni(p, key) * 2 - 1) * 0.05
+        p.copy_(v.to(p.dtype))
+    return model
+
+
+def portable_randn(shape, key, device='cpu', dtype=torch.float32):
+    """Device-independent N(0, 1)-like tensor (Irwin-Hall of the integer hash above) for golden inputs."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    u = sum(_hash_uniform(n, int(key) * 7919 + j, device) for j in range(4))
+    return ((u - 2.0) * 1.7320508).view(*shape).to(dtype)

@@ -243,7 +243,7 @@ class TemporalTransformer3DModel(nn.Module):
         y = self.norm(x, bf)
         y = self.proj_in(y.view(bf, h * w, c))
         shard = geo.site_shard
-        if shard is None:
+        if shard is None or not shard.use_sites(h * w):
             for block in self.transformer_blocks:
                 y = block(y, video_length=geo.F)
         else:
@@ -252,8 +252,12 @@ class TemporalTransformer3DModel(nn.Module):
             inner = y.shape[-1]
             ys = shard.to_sites(y.view(-1, inner), geo.B, h * w)
             ys = ys.view(geo.B * shard.total_frames, -1, inner)
-            for block in self.transformer_blocks:
-                ys = block(ys, video_length=shard.total_frames)
+            shard.kv_active = False              # all frames of these sites are local: no K|V gather in the blocks
+            try:
+                for block in self.transformer_blocks:
+                    ys = block(ys, video_length=shard.total_frames)
+            finally:
+                shard.kv_active = True
             y = shard.to_frames(ys.view(-1, inner), geo.B, h * w).view(bf, h * w, inner)
         y = self.proj_out(y, residual=x.view(bf, h * w, c))
         return y.view(bf, h, w, c)
@@ -630,7 +634,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         B, _, F, H, W = sample.shape
         shard = self._frame_shard
         geo = Geometry(B, F, None if shard is None else shard.gn_hook, None if shard is None else shard.total_frames,
-                       shard if shard is not None and shard.exchange == 'sites' else None)
+                       shard if shard is not None and shard.exchange != 'kv' else None)
 
         x = ops.pack_latents(sample.contiguous(), 8)            # [B*F, H, W, 8] (latent channels zero-padded)
         x = self.conv_in(x)
