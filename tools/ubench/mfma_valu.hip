@@ -39,6 +39,24 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* __restrict__ sink, lo
     for (int e = 0; e < 8; ++e) v[e] = 0.01f * (lane + e);
     __syncthreads();
     const long t0 = (long)__builtin_amdgcn_s_memtime();
+    if (MODE == 3) {
+        // role fixed per wave OUTSIDE the loop: two tight loops (round-3 run 2: with the role tested inside one shared loop
+        // an MFMA-only wave took 1145 ticks per iteration instead of 449 — the branch-around structure itself cost more
+        // than the work, so that table said nothing about overlap)
+        if (do_mfma) {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int m = 0; m < NM; ++m) acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m & 3], 0, 0, 0);
+            }
+        } else {
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int k = 0; k < NEXP; ++k) v[k & 7] = __builtin_amdgcn_exp2f(v[k & 7] * 0.5f - 1.0f);
+#pragma unroll
+                for (int k = 0; k < NFMA; ++k) v[k & 7] = __builtin_fmaf(v[k & 7], 0.999f, 0.001f * v[(k + 3) & 7]);
+            }
+        }
+    } else
     for (int it = 0; it < iters; ++it) {
         if (do_mfma) {
 #pragma unroll
@@ -69,6 +87,8 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* __restrict__ sink, lo
     if (lane == 0) cycles[blockIdx.x * WAVES + wave] = t1 - t0;
 }
 
+static double g_role[2];
+
 template <int MODE, int WAVES>
 static double run(float* sink, long* cyc, int blocks, int iters) {
     hipLaunchKernelGGL((probe<MODE, WAVES>), dim3(blocks), dim3(64 * WAVES), 0, 0, sink, cyc, iters);
@@ -76,8 +96,14 @@ static double run(float* sink, long* cyc, int blocks, int iters) {
     std::vector<long> h(blocks * WAVES);
     (void)hipMemcpy(h.data(), cyc, h.size() * sizeof(long), hipMemcpyDeviceToHost);
     double mx = 0;
-    for (long c : h) mx = c > mx ? (double)c : mx;
-    return mx / iters;          // s_memtime ticks (100 MHz constant clock on gfx9: multiply by core clock / 100 MHz)
+    g_role[0] = g_role[1] = 0;
+    for (size_t i = 0; i < h.size(); ++i) {
+        const double c = (double)h[i];
+        mx = c > mx ? c : mx;
+        const int role = ((i % WAVES) >> 2) & 1;                 // split mode: 0 = MFMA wave, 1 = VALU wave
+        g_role[role] = c / iters > g_role[role] ? c / iters : g_role[role];
+    }
+    return mx / iters;          // s_memtime ticks
 }
 
 template <int WAVES>
@@ -85,12 +111,14 @@ static void table(float* sink, long* cyc, int blocks, int iters) {
     // s_memtime counts a fixed-frequency clock: report ratios, which are what matters
     const double m = run<0, WAVES>(sink, cyc, blocks, iters), v = run<1, WAVES>(sink, cyc, blocks, iters);
     const double b = run<2, WAVES>(sink, cyc, blocks, iters), s = run<3, WAVES>(sink, cyc, blocks, iters);
+    const double rm = g_role[0], rv = g_role[1];
     const double il = run<4, WAVES>(sink, cyc, blocks, iters);
     // split does half of the `mfma` work and half of the `valu` work per SIMD: no overlap -> (mfma + valu) / 2,
     // perfect overlap across waves -> max(mfma, valu) / 2
     printf("%2d waves per CU (%d per SIMD): mfma %8.2f  valu %8.2f  same-wave %8.2f (%.2f x (mfma + valu))  "
-           "interleaved same-wave %8.2f  split %8.2f (no overlap would be %.2f, perfect overlap %.2f)\n", WAVES, WAVES / 4,
-           m, v, b, b / (m + v), il, s, WAVES >= 8 ? (m + v) / 2 : m, WAVES >= 8 ? (m > v ? m : v) / 2 : m);
+           "interleaved same-wave %8.2f  split %8.2f [MFMA waves %.2f, VALU waves %.2f] (no overlap would be %.2f, perfect "
+           "overlap %.2f)\n", WAVES, WAVES / 4, m, v, b, b / (m + v), il, s, rm, rv, WAVES >= 8 ? (m + v) / 2 : m,
+           WAVES >= 8 ? (m > v ? m : v) / 2 : m);
 }
 
 int main() {

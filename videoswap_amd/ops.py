@@ -5,6 +5,7 @@ PyTorch is used for device memory and the HIP stream only: every function here t
 returns the output tensor.  There is no fallback implementation.
 """
 import ctypes
+import os
 
 import torch
 
@@ -61,7 +62,19 @@ class FlopCounter:
 _split_ws = {}      # (device, stream) -> grow-only fp32 scratch for split-K partial sums (stream-ordered reuse)
 
 
+# VSX_GEMM_LOG=<file>: one line per vsx_gemm_f16 launch (shape, loader mode, epilogue), in launch order — joined by
+# tools/pmc_by_shape.py with rocprofv3's per-dispatch counters (the i-th GEMM dispatch is the i-th line).  Measurement only.
+_gemm_log = None
+if os.environ.get('VSX_GEMM_LOG'):
+    _gemm_log = open(os.environ['VSX_GEMM_LOG'], 'w')
+
+
 def gemm(desc):
+    if _gemm_log is not None:
+        _gemm_log.write(f'{desc.M} {desc.N} {desc.K} {desc.batch0 * desc.batch1} {desc.a_mode} {desc.ks} {desc.stride} '
+                        f'{desc.upsample} {desc.C1} {desc.C2} {desc.H} {desc.W} {desc.geglu} {desc.c_mode} '
+                        f'{1 if desc.residual else 0} {1 if desc.rowvec else 0} {1 if desc.bias else 0}\n')
+        _gemm_log.flush()
     if FlopCounter.enabled:
         cols = desc.N * (2 if desc.geglu else 1)
         FlopCounter.gemm += 2.0 * desc.M * cols * desc.K * desc.batch0 * desc.batch1
