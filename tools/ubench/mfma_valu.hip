@@ -29,8 +29,9 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* __restrict__ sink, lo
     // every wave only does MFMAs, took as long as `same-wave`)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // waves w, w+4, w+8 ... share SIMD w % 4; "parity within the SIMD" = (wave / 4) & 1
-    const bool do_mfma = MODE == 0 || MODE == 2 || MODE == 4 || (MODE == 3 && ((wave >> 2) & 1) == 0);
-    const bool do_valu = MODE == 1 || MODE == 2 || MODE == 4 || (MODE == 3 && ((wave >> 2) & 1) == 1);
+    const bool split = MODE == 3 || MODE == 5 || MODE == 6;
+    const bool do_mfma = MODE == 0 || MODE == 2 || MODE == 4 || (split && ((wave >> 2) & 1) == 0);
+    const bool do_valu = MODE == 1 || MODE == 2 || MODE == 4 || (split && ((wave >> 2) & 1) == 1);
     h8 a, b;
     for (int e = 0; e < 8; ++e) { a[e] = (_Float16)(0.001f * (lane + e)); b[e] = (_Float16)(0.002f * (lane - e)); }
     f16v acc[4];
@@ -39,7 +40,9 @@ __global__ __launch_bounds__(64 * WAVES) void probe(float* __restrict__ sink, lo
     for (int e = 0; e < 8; ++e) v[e] = 0.01f * (lane + e);
     __syncthreads();
     const long t0 = (long)__builtin_amdgcn_s_memtime();
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 5 || MODE == 6) {
+        if (MODE == 5 && !do_mfma) __builtin_amdgcn_s_setprio(3);
+        if (MODE == 6 && do_mfma) __builtin_amdgcn_s_setprio(3);
         // role fixed per wave OUTSIDE the loop: two tight loops (round-3 run 2: with the role tested inside one shared loop
         // an MFMA-only wave took 1145 ticks per iteration instead of 449 — the branch-around structure itself cost more
         // than the work, so that table said nothing about overlap)
@@ -113,12 +116,19 @@ static void table(float* sink, long* cyc, int blocks, int iters) {
     const double b = run<2, WAVES>(sink, cyc, blocks, iters), s = run<3, WAVES>(sink, cyc, blocks, iters);
     const double rm = g_role[0], rv = g_role[1];
     const double il = run<4, WAVES>(sink, cyc, blocks, iters);
+    const double s5 = run<5, WAVES>(sink, cyc, blocks, iters);
+    const double rm5 = g_role[0], rv5 = g_role[1];
+    const double s6 = run<6, WAVES>(sink, cyc, blocks, iters);
+    const double rm6 = g_role[0], rv6 = g_role[1];
     // split does half of the `mfma` work and half of the `valu` work per SIMD: no overlap -> (mfma + valu) / 2,
     // perfect overlap across waves -> max(mfma, valu) / 2
     printf("%2d waves per CU (%d per SIMD): mfma %8.2f  valu %8.2f  same-wave %8.2f (%.2f x (mfma + valu))  "
            "interleaved same-wave %8.2f  split %8.2f [MFMA waves %.2f, VALU waves %.2f] (no overlap would be %.2f, perfect "
            "overlap %.2f)\n", WAVES, WAVES / 4, m, v, b, b / (m + v), il, s, rm, rv, WAVES >= 8 ? (m + v) / 2 : m,
            WAVES >= 8 ? (m > v ? m : v) / 2 : m);
+    if (WAVES >= 8)
+        printf("      split with the VALU waves at s_setprio 3: %8.2f [MFMA waves %.2f, VALU waves %.2f];  with the MFMA waves at "
+               "s_setprio 3: %8.2f [MFMA waves %.2f, VALU waves %.2f]\n", s5, rm5, rv5, s6, rm6, rv6);
 }
 
 int main() {

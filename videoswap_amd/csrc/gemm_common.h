@@ -28,7 +28,14 @@ struct GemmParams {
     float* ws;
     float alpha;
     int tiles_total;                       // persistent kernel: number of output tiles
+    int pp_flags;                          // persistent kernel: PP_* option bits (tile walk, conv slab order, priority)
 };
+
+// pp_flags (option "pp_sched" / VSX_PP_SCHED, bits above the piece-schedule variant in bits 0-1)
+constexpr int PP_KORDER_TAP_INNER = 4;    // conv: walk the 9 taps of a 64-channel slab before the next slab (L2 reuse)
+constexpr int PP_TILES_2D = 8;            // wide N: the 32 workgroups of an XCD hold an (RB x CB) block of tiles at a time
+constexpr int PP_PRIO_NONE = 16;          // no s_setprio around the MFMA phase
+constexpr int PP_PRIO_LOAD = 32;          // s_setprio 1 around the LOAD phase instead
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
