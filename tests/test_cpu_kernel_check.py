@@ -1,5 +1,5 @@
 """Kernels executed FROM THEIR SOURCE on the CPU (tools/cpu_check): the backward kernels of the training step and the
-development library's persistent MFMA GEMM / conv kernel with its candidate piece schedules.
+persistent MFMA GEMM / conv kernel with its schedule / option variants.
 
 The backward kernels of the training step (videoswap_amd/csrc/train.hip) executed FROM THEIR SOURCE on the
 CPU: tools/cpu_check/hip/hip_runtime.h maps the HIP execution model of these simple kernels (a workgroup = OS threads,
@@ -36,12 +36,13 @@ def test_backward_kernels_run_from_source_on_the_cpu(tmp_path):
 
 @pytest.mark.skipif(not (os.path.isfile(CXX) or shutil.which('clang++')), reason='needs clang++ (C++20, _Float16)')
 def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
-    """videoswap_amd/csrc/experimental/gemm_pp.hip under tools/cpu_check/hip_gemm.h (MFMA as a wave collective with the
-    hardware's fragment layout, LDS-DMA as a synchronous 16-byte-per-lane copy with the descriptor's range check, wave
-    lockstep at the scheduling barriers): every candidate schedule — pieces issued inside the MFMA phases (3-6), packed B
-    (+16) — must reproduce a double-precision GEMM / convolution and agree bit for bit with schedule 0, without a single
-    read past a tensor.  (What this cannot see is the asynchronous ordering of the real DMA: DESIGN.md §8 argues that
-    separately.)  A subset of `make -C tools/cpu_check run`: one case per epilogue / loader kind."""
+    """videoswap_amd/csrc/gemm_pp.hip (the shipped persistent kernel) under tools/cpu_check/hip_gemm.h (MFMA as a wave
+    collective with the hardware's fragment layout, LDS-DMA as a synchronous 16-byte-per-lane copy with the descriptor's
+    range check, wave lockstep at the scheduling barriers): every piece schedule of `pp_sched`, under the default 2-D
+    tile walk and under the linear one (+ 8), must reproduce a double-precision GEMM / convolution, bit for bit like
+    variant 0, without a single read past a tensor.  (What this cannot see is the
+    asynchronous ordering of the real DMA; the late-landing run below covers the other extreme of it.)  A subset of
+    `make -C tools/cpu_check run`: one case per epilogue / loader kind."""
     cxx = CXX if os.path.isfile(CXX) else shutil.which('clang++')
     src = os.path.join(ROOT, 'tools', 'cpu_check')
     exe = str(tmp_path / 'check_gemm_pp')
@@ -50,17 +51,18 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
            os.path.join(src, 'check_gemm_pp.cpp')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    runs = [('0', '0,1,2,3,4,5,6,16,19,20'),     # one 256x320 tile, one slab: every schedule
-            ('4', '0,16'),                       # GEGLU epilogue
-            ('6', '0,5'),                        # 128-row tiles, GEGLU, ragged M
-            ('7', '3,20')]                       # 3x3 convolution, two sources
+    runs = [('0', '0,1,2,8'),                    # one 256x320 tile, one slab: every variant
+            ('4', '0,1'),                        # GEGLU epilogue
+            ('6', '0,2'),                        # 128-row tiles, GEGLU, ragged M
+            ('7', '0,8'),                        # 36 tiles, tiles_n = 12: the 2-D walk against the linear one
+            ('8', '0,2')]                        # 3x3 convolution, two sources
     for case, scheds in runs:
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900)
         print(r.stdout)
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     # ordering hazards: the multi-tile, multi-slab case again with every DMA piece landing as LATE as the kernel's own
     # waits allow (the default run above lands them at issue, the other extreme); see tools/cpu_check/hip_gemm.h
-    r = subprocess.run([exe, '1', '0,4,20'], capture_output=True, text=True, timeout=900,
+    r = subprocess.run([exe, '1', '0,2,8'], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, CPUHIP_DMA='late'))
     print(r.stdout)
     assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

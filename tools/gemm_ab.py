@@ -3,8 +3,7 @@ persistent ping-pong kernel with 256-row tiles (gemm_pp = 2), with 128-row tiles
 (gemm_pp = 1, what the product runs).
 
     python tools/gemm_ab.py [--batch 2] [--rounds 5] > gpurun_out/gemm_ab.txt
-    VSX_LIB_VARIANT=next python tools/gemm_ab.py --scheds 0,4,32,36,64,68 # + 32: MFMAs left out, + 64: DMA left out
-    VSX_LIB_VARIANT=next python tools/gemm_ab.py --scheds 0,3,4,5,6      # piece schedules of the development library:
+    python tools/gemm_ab.py --scheds 0,4,8,12,16,32    # option bits of pp_sched (gemm_common.h PP_*):
                                                                           # tile kernels vs 256-row persistent tiles per schedule
 
 Variants are interleaved round by round inside ONE process (a cross-process comparison has >3 % noise); the table shows
@@ -102,19 +101,13 @@ def main():
     ap.add_argument('--reps', type=int, default=4)
     ap.add_argument('--scheds', default='', help='comma-separated pp_sched values: compare piece schedules instead of tile sizes')
     ap.add_argument('--bm', type=int, default=256, choices=(128, 256), help='row tile of the --scheds comparison')
-    ap.add_argument('--bpack', action='store_true',
-                    help='with --scheds: add every schedule >= 16 as a packed-B variant (development library only); the '
-                         'packed result must equal the unpacked one bit for bit')
     args = ap.parse_args()
     variants = [('tile', 0, 0), ('pp256', 2, 0), ('pp128', 3, 0), ('auto', 1, 0)]
     if args.scheds:
-        def label(n):
+        def label(n):           # pp_sched bits: 0-1 piece cut, 4 conv slab order, 8 2-D tile walk, 16 no prio, 32 prio on LOAD
             n = int(n)
-            kind = 'noDMA' if n >= 64 else 'noMFMA' if n >= 32 else f'pp{args.bm}'
-            return f'{kind}/s{n & 15}' + ('p' if n & 16 else '')
+            return f'pp{args.bm}/s{n}'
         variants = [('tile', 0, 0)] + [(label(n), 2 if args.bm == 256 else 3, int(n)) for n in args.scheds.split(',')]
-        if not args.bpack and any(v[2] & 16 and v[2] < 32 for v in variants):
-            raise SystemExit('schedules >= 16 read a packed B operand: add --bpack')
     print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
     print(f'{"shape":44s} {"n":>3s} ' + ' '.join(f'{v[0]:>9s}' for v in variants) + '   best TF/s  speedup  fwd-ms tile -> best')
     tot_old = tot_best = 0.0
@@ -122,18 +115,13 @@ def main():
         torch.manual_seed(0)
         fn, flop = make(kind, a)
         fns = {v[0]: fn for v in variants}
-        if args.bpack:
-            torch.manual_seed(0)                # same operands, B piece-major
-            fn_packed, _ = make(kind, a, packed=True)
-            fns.update({v[0]: fn_packed for v in variants if v[2] & 16 and v[2] < 32})
         ts = {v[0]: [] for v in variants}
         outs = {}
         for v in variants:                      # warm every variant (first launch sets the LDS attribute)
             ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2])
             outs[v[0]] = fns[v[0]]()
         torch.cuda.synchronize()
-        diag = {v[0] for v in variants if v[2] >= 32}           # measurement-only variants: their output is garbage
-        bad = [k for k, o in outs.items() if k not in diag and not torch.equal(o, outs['tile'])]
+        bad = [k for k, o in outs.items() if not torch.equal(o, outs['tile'])]
         if bad:
             print(f'# {name}: variants differing from the tile kernels: {bad}')
         del outs

@@ -157,7 +157,7 @@ void loop4(const half_t* __restrict__ A, const half_t* __restrict__ B, float* __
 // variant 8: the shipped ping-pong structure (8 waves of 64x160, a barrier per phase), same harness
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void loop8(const half_t* __restrict__ A, const half_t* __restrict__ B,
-                                             float* __restrict__ sink, int K, int nslab) {
+                                             float* __restrict__ sink, int K, int nslab, int a_private, int b_private, int stagger) {
     constexpr int TM = 2, TN = 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -166,14 +166,18 @@ __global__ __launch_bounds__(512) void loop8(const half_t* __restrict__ A, const
     const int l31 = lane & 31, hi = lane >> 5;
     const unsigned ld2 = (unsigned)K * 2u;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<half_t*>(A + (size_t)blockIdx.x * BM * K), 0, BM * K * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(B), 0, BN * K * 2, 0x00020000);
+        const_cast<half_t*>(A + (a_private ? (size_t)blockIdx.x * BM * K : 0)), 0, BM * K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(B + (b_private ? (size_t)blockIdx.x * BN * K : 0)), 0, BN * K * 2, 0x00020000);
+    const int k_start = stagger * (int)(blockIdx.x >> 3);
     const int lrow = lane >> 3, pslot = lane & 7;
     const int kofs_e = (pslot ^ (lrow >> 1)) * 16, kofs_o = (pslot ^ (4 | (lrow >> 1))) * 16;
     const int v_e = (int)((unsigned)lrow * ld2) + kofs_e, v_o = (int)((unsigned)lrow * ld2) + kofs_o;
     auto issue = [&](const int q, const int slab) {          // 9 pieces per wave: 4 of A, 5 of B
         const int slot = (slab & 1) * STAGE;
-        const unsigned koff = (unsigned)(slab % (K / BKH)) * 128u;
+        // stagger: workgroup w of an XCD starts its K sweep `stagger * w` slabs further (the CUs of an XCD then read
+        // different lines of a shared panel at any moment instead of all hitting the same L2 lines together)
+        const unsigned koff = (unsigned)((slab + k_start) % (K / BKH)) * 128u;
         if (q < 4) {
             const int pc = wave * 4 + q;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(smem + slot + pc * 1024), 16, (pc & 1) ? v_o : v_e,
@@ -267,9 +271,10 @@ int main(int argc, char** argv) {
     const int nwg = argc > 1 ? atoi(argv[1]) : 256;
     const int K = argc > 2 ? atoi(argv[2]) : 2560;            // K elements of the operand panels (re-swept)
     const int nslab = argc > 3 ? atoi(argv[3]) : 160;
+    const int mode = argc > 4 ? atoi(argv[4]) : 0;            // 0: all variants; 1: variant 8 only, A/B sharing sweep
     half_t *A, *B;
     float* sink;
-    const size_t na = (size_t)nwg * BM * K, nb = (size_t)BN * K;
+    const size_t na = (size_t)nwg * BM * K, nb = (size_t)(mode ? nwg : 1) * BN * K;
     (void)hipMalloc(&A, na * 2);
     (void)hipMalloc(&B, nb * 2);
     (void)hipMalloc(&sink, (size_t)nwg * 512 * 4);
@@ -280,13 +285,26 @@ int main(int argc, char** argv) {
     const size_t smem = 2 * STAGE;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&loop8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const double flop = 2.0 * BM * BN * BKH * (double)nslab * nwg;
-    printf("# %d workgroups, K panel %d (A %.1f MB private per launch, B %.2f MB shared), %d slabs per tile: %.1f GFLOP\n", nwg, K,
-           na * 2 / 1e6, nb * 2 / 1e6, nslab, flop / 1e9);
+    printf("# %d workgroups, K panel %d (A %.1f MB if private, B %.2f MB per panel), %d slabs per tile: %.1f GFLOP\n", nwg, K,
+           na * 2 / 1e6, (double)BN * K * 2 / 1e6, nslab, flop / 1e9);
     auto report = [&](const char* name, double us) {
-        printf("%-46s %9.1f us  %7.1f TF/s  %.3f of 2.5 PF/s\n", name, us, flop / us / 1e6, flop / us / 1e6 / 2500.0);
+        printf("%-58s %9.1f us  %7.1f TF/s  %.3f of 2.5 PF/s\n", name, us, flop / us / 1e6, flop / us / 1e6 / 2500.0);
     };
+    if (mode) {
+        for (int st : {0, 1, 3, 7})
+            for (int ap = 1; ap >= 0; --ap)
+                for (int bp = 0; bp <= (st ? 0 : 1); ++bp) {
+                    char name[96];
+                    snprintf(name, sizeof(name), "8 waves ping-pong, A %s, B %s, K start + %d x wg", ap ? "private" : "shared ",
+                             bp ? "private" : "shared ", st);
+                    report(name, time_us([&] {
+                        hipLaunchKernelGGL(loop8, dim3(nwg), dim3(512), smem, 0, A, B, sink, K, nslab, ap, bp, st); }, 5));
+                }
+        printf("status %s\n", hipGetErrorString(hipGetLastError()));
+        return 0;
+    }
     report("8 waves, ping-pong, barrier per phase", time_us([&] {
-        hipLaunchKernelGGL(loop8, dim3(nwg), dim3(512), smem, 0, A, B, sink, K, nslab); }, 5));
+        hipLaunchKernelGGL(loop8, dim3(nwg), dim3(512), smem, 0, A, B, sink, K, nslab, 1, 0, 0); }, 5));
 #define RUN4(TM, N0, N1)                                                                                                \
     {                                                                                                                   \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&loop4<TM, N0, N1>),                                    \

@@ -5,10 +5,11 @@
 hipcc cross-compiles for gfx950 without a GPU.  The shared library lands in videoswap_amd/lib/
 (git-ignored, but it travels with the gpurun snapshot).
 
-Variants: `--variant next` builds lib/libvsx_next.so from the same sources with the files listed in VARIANTS swapped
-for their csrc/experimental/ versions — kernels under development that have not been measured yet.  The product loads
-libvsx.so; `VSX_LIB_VARIANT=next` makes `videoswap_amd._lib` load the variant instead (tools/gemm_ab.py and the kernel
-tests then run against it), so that a candidate can be A/B-ed on the GPU without touching the measured library.
+Variants: VARIANTS / VARIANT_EXTRA can name a development build (lib/libvsx_<name>.so with some sources swapped or
+added; `VSX_LIB_VARIANT=<name>` makes `videoswap_amd._lib` load it) so that a candidate kernel can be A/B-ed on the GPU
+without touching the measured library.  None exists at the moment: round 3 ran the round-2 candidates on hardware,
+promoted the backward kernels and the strided all-to-all into libvsx.so and dropped the piece-schedule / packed-weight
+fork of the persistent GEMM (no gain: profiles/r03_gemm_sched_ab_b2.txt, r03_gemm_bpack_ab_b2.txt).
 """
 import hashlib
 import os
@@ -23,7 +24,7 @@ LIBDIR = os.path.join(HERE, 'lib')
 OBJDIR = os.path.join(LIBDIR, 'obj')
 LIB = os.path.join(LIBDIR, 'libvsx.so')
 # variant name -> {source file of SOURCES: replacement, relative to csrc/}
-VARIANTS = {'next': {'gemm_pp.hip': 'experimental/gemm_pp.hip'}}
+VARIANTS = {}
 # variant name -> additional sources (relative to csrc/)
 VARIANT_EXTRA = {}
 SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'train.hip']

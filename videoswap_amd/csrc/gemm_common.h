@@ -31,11 +31,13 @@ struct GemmParams {
     int pp_flags;                          // persistent kernel: PP_* option bits (tile walk, conv slab order, priority)
 };
 
-// pp_flags (option "pp_sched" / VSX_PP_SCHED, bits above the piece-schedule variant in bits 0-1)
-constexpr int PP_KORDER_TAP_INNER = 4;    // conv: walk the 9 taps of a 64-channel slab before the next slab (L2 reuse)
-constexpr int PP_TILES_2D = 8;            // wide N: the 32 workgroups of an XCD hold an (RB x CB) block of tiles at a time
-constexpr int PP_PRIO_NONE = 16;          // no s_setprio around the MFMA phase
-constexpr int PP_PRIO_LOAD = 32;          // s_setprio 1 around the LOAD phase instead
+// pp_flags: option bits of "pp_sched" / VSX_PP_SCHED above the piece-schedule variant (bits 0-1).  Round 3 measured five
+// candidates on the GPU (profiles/r03_gemm_option_ab*_b2.txt) and kept one: the 2-D tile walk inside an XCD is the default
+// (same speed, 2.5x less HBM traffic on the wide-N GEMMs); 8 restores the linear walk for A/B runs.  Dropped: conv slab
+// order "taps of a channel slab back to back" (8-13 % slower: the per-slab address update runs on the VALU, which is
+// blocked while the partner wave streams MFMAs), no s_setprio / s_setprio on the LOAD phase (+-1 %), K-start stagger per
+// workgroup (+5-9 % in tools/ubench/gemm_loop.hip, -6 ... +10 % in the kernel: no net gain).
+constexpr int PP_TILES_LINEAR = 8;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 

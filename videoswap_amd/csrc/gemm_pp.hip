@@ -64,10 +64,11 @@ __device__ __forceinline__ kparams_t kernarg_params() {
 // (GEGLU) / 320, so there is no column edge; rows >= M are skipped.
 constexpr int EP_BYTES = 10240;     // staging bytes per wave: 32 rows x (64 + 4) floats = 8704
 
-// Tile index -> (tile_m, tile_n).  Default walk: N fastest.  PP_TILES_2D (tiles_n a multiple of 4 and > 8): the walk goes
+// Tile index -> (tile_m, tile_n).  Narrow problems (and PP_TILES_LINEAR): N fastest.  tiles_n a multiple of 4 and > 8: the walk goes
 // block by block through super-rows of RB row tiles, a block being RB x CB tiles (RB * CB = 32 = the workgroups an XCD
 // runs at a time), so that at any moment an XCD's CUs share RB activation panels and CB weight panels in L2 instead of
-// 1 and 32 (geglu 1280->5120: every XCD used to stream the whole 26 MB weight matrix once per row tile).
+// 1 and 32 (geglu 1280->5120: every XCD used to stream the whole 26 MB weight matrix once per row tile: 945 MB of HBM
+// traffic per launch against 131 MB algorithmic, 378 MB with this walk at the same speed — profiles/r03_gemm_traffic_by_shape_*.txt).
 __device__ __forceinline__ void tile_coords(const int tile, const int tiles_n, const int tiles_m, const bool blocked,
                                             int& tile_m, int& tile_n) {
     const int CB = (tiles_n & 7) == 0 ? 8 : 4;
@@ -265,10 +266,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     const int Mi = (int)p->M;
     const int tiles_n = p->tiles_n;
     const int flags = p->pp_flags;
-    const bool blocked = (flags & PP_TILES_2D) != 0;
-    const bool tap_inner = CONV && (flags & PP_KORDER_TAP_INNER) != 0;
-    const int prio_mma = (flags & (PP_PRIO_NONE | PP_PRIO_LOAD)) ? 0 : 1;
-    const int prio_load = (flags & PP_PRIO_LOAD) ? 1 : 0;
+    const bool blocked = (flags & PP_TILES_LINEAR) == 0;
     const int tiles_m = (Mi + BM - 1) / BM;
     const int geglu = p->geglu;
     const int K = (int)p->K;
@@ -352,30 +350,15 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             // K index of this slab in the weight rows (OHWI: tap-major, then source 1 | source 2 channels)
             const unsigned k0 = (unsigned)((t_kh * ks + t_kw) * (C1 + C2) + (t_second ? C1 : 0) + t_c);
             i_soffB = i_rowB + k0 * 2u;
-            if (tap_inner) {
-                // the ks*ks taps of one 64-channel slab back to back: their A windows are shifts of the same input rows,
-                // so the taps after the first hit L2 (tap-major order re-reads the input from the fabric once per tap:
-                // profiles/r03_gemm_traffic_by_shape.txt, 3.8-7.6x the algorithmic bytes on the convolutions)
+            t_c += BK;
+            if (t_c >= (t_second ? C2 : C1)) {          // next source or next tap
+                t_c = 0;
                 t_dirty = true;
-                if (++t_kw == ks) {
-                    t_kw = 0;
-                    if (++t_kh == ks) {
-                        t_kh = 0;
-                        t_c += BK;
-                        if (t_c >= (t_second ? C2 : C1)) { t_c = 0; t_second = true; }     // past source 2: tile done
-                    }
-                }
-            } else {
-                t_c += BK;
-                if (t_c >= (t_second ? C2 : C1)) {          // next source or next tap
-                    t_c = 0;
-                    t_dirty = true;
-                    if (!t_second && C2 > 0) {
-                        t_second = true;
-                    } else {
-                        t_second = false;
-                        if (++t_kw == ks) { t_kw = 0; ++t_kh; }
-                    }
+                if (!t_second && C2 > 0) {
+                    t_second = true;
+                } else {
+                    t_second = false;
+                    if (++t_kw == ks) { t_kw = 0; ++t_kh; }
                 }
             }
         } else {
@@ -477,52 +460,44 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             i_on = i_t < n_my;
             if (i_on) slab_prep();              // the slab that streams in while this one is multiplied
             // ---- k-step 0 ----
-            if (prio_load) __builtin_amdgcn_s_setprio(1);
             ldfrag(so, 0);
             __builtin_amdgcn_sched_barrier(0);
             issue_range(0, CUT1);
             lgkm0();
-            if (prio_load) __builtin_amdgcn_s_setprio(0);
             bar();
-            if (prio_mma) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
             if (kt == 0) mma_first(); else mma();
-            if (prio_mma) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             bar();
             // ---- k-step 1 ----
-            if (prio_load) __builtin_amdgcn_s_setprio(1);
             ldfrag(so, 1);
             __builtin_amdgcn_sched_barrier(0);
             issue_range(CUT1, CUT2);
             lgkm0();
-            if (prio_load) __builtin_amdgcn_s_setprio(0);
             bar();
-            if (prio_mma) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
             mma();
-            if (prio_mma) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             bar();
             // ---- k-step 2 ----
-            if (prio_load) __builtin_amdgcn_s_setprio(1);
             ldfrag(so, 2);
             __builtin_amdgcn_sched_barrier(0);
             issue_range(CUT2, NPIECE);
             lgkm0();
-            if (prio_load) __builtin_amdgcn_s_setprio(0);
             bar();
-            if (prio_mma) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
             mma();
-            if (prio_mma) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             bar();
             // ---- k-step 3 ----
-            if (prio_load) __builtin_amdgcn_s_setprio(1);
             ldfrag(so, 3);
             __builtin_amdgcn_sched_barrier(0);
             if (G == 1) wait_vmcnt<0>();        // G1's pieces of the next slab (issued in its L0..L2) have landed
             lgkm0();
-            if (prio_load) __builtin_amdgcn_s_setprio(0);
             bar();
-            if (prio_mma) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
             mma();
-            if (prio_mma) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             if (G == 0) wait_vmcnt<0>();        // G0's pieces: waited behind its last MFMAs
             if (kt + 1 < nk) bar();
@@ -601,7 +576,7 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     // the compiled variants
     const long opt = gemm_option("pp_sched");
     const int variant = (int)(opt & 3);
-    p.pp_flags = (int)(opt & ~3L);
+    p.pp_flags = (int)(opt & PP_TILES_LINEAR);
     const bool conv = p.a_mode == 1;
     if (bm == 256) {                            // 9 pieces per wave and slab
         if (variant == 1) return conv ? launch_one<2, true, 4, 7>(p, stream) : launch_one<2, false, 4, 7>(p, stream);
