@@ -215,10 +215,10 @@ def torch_rocm_baseline(device, frames=16, latent=64, repeats=2):
 
 
 def gemm_traffic(frames, latent):
-    """HBM bytes per vsx_gemm_f16 launch from the PMC passes of tools/pmc_traffic.sh — only if that file was measured
+    """HBM bytes per vsx_gemm_f16 launch from the PMC passes of tools/pmc_by_shape.sh — only if that file was measured
     on THIS build of the library (source digest) at the benchmark shape; a stale file is not a measurement."""
     from videoswap_amd.build import source_digest
-    path = os.path.join(ROOT, 'profiles', 'r02_gemm_hbm_traffic.json')
+    path = os.path.join(ROOT, 'profiles', 'gemm_hbm_traffic.json')
     if not os.path.exists(path) or frames != 16 or latent != 64:
         return None, 'no PMC traffic file for this shape'
     with open(path) as f:

@@ -108,6 +108,16 @@ def main(root):
         print(line)
     print(f'# total: algorithmic {tot_alg / 1e9:.2f} GB, measured {tot_hbm / 1e9:.2f} GB = {tot_hbm / tot_alg:.2f}x; '
           f'{tot_hbm / n / 1e6:.1f} MB per launch; GEMM time {tot_t * 1e3:.2f} ms')
+    # the aggregate bench.py reports as roofline.traffic (valid for the library build whose digest it carries)
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from videoswap_amd.build import source_digest
+    with open(os.path.join(root, 'gemm_hbm_traffic.json'), 'w') as f:
+        json.dump({'kernel': 'vsx_gemm_f16 (all shapes of one inversion step + one CFG step)', 'launches': n,
+                   'lib_digest': source_digest(), 'hbm_bytes_per_launch': tot_hbm / n,
+                   'algorithmic_bytes_per_launch': tot_alg / n, 'ratio': tot_hbm / tot_alg,
+                   'note': 'FETCH_SIZE x 2 (gfx950 reports half the bytes of wide coalesced reads) + WRITE_SIZE, separate '
+                           '--pmc passes, tools/pmc_by_shape.sh'}, f, indent=1)
 
 
 if __name__ == '__main__':

@@ -34,6 +34,28 @@ def main(path):
                 big += g
                 nbig += 1
         hi = max(hi, en)
+    # distribution of the sub-ms gaps, and which kernel they follow (the dispatch that just finished): a gap is the
+    # command processor's dependent-launch latency plus whatever the host had not yet queued
+    evn = c.execute(f'select start, end, {name_col} from kernels order by start').fetchall()
+    gaps, after = [], {}
+    hi2 = evn[0][1] if evn else 0
+    prev = evn[0][2] if evn else ''
+    for st, en, nm in evn[1:]:
+        g = max(0, st - hi2)
+        if g < 1_000_000:
+            gaps.append(g)
+            a = after.setdefault(prev.split('(')[0][-60:], [0, 0])
+            a[0] += 1
+            a[1] += g
+        if en >= hi2:
+            hi2, prev = en, nm
+    if gaps:
+        gs = sorted(gaps)
+        print(f'# gaps < 1 ms: median {gs[len(gs) // 2] / 1e3:.2f} us, mean {sum(gs) / len(gs) / 1e3:.2f} us, p90 '
+              f'{gs[int(0.9 * len(gs))] / 1e3:.2f} us, p99 {gs[int(0.99 * len(gs))] / 1e3:.2f} us; '
+              f'{sum(1 for g in gs if g > 20000)} gaps > 20 us carry {sum(g for g in gs if g > 20000) / 1e6:.2f} ms')
+        for k, (n, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:8]:
+            print(f'#   after {k:60s} {n:6d} gaps, {t / 1e6:8.3f} ms, {t / n / 1e3:6.2f} us each')
     if ev:
         span = hi - ev[0][0]
         print(f'# span {span / 1e6:.3f} ms; idle between dispatches: {small / 1e6:.3f} ms in {nsmall} gaps < 1 ms '

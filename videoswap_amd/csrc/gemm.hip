@@ -1044,11 +1044,15 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     // shape is eligible.
     const int pp = pp_mode();
     const bool pp_ok = pp != 0 && wide && nbatch == 1 && (splits <= 1 || pp >= 2) && !force_tile() && pp_supported(p);
-    // option gemm_pp: 0 never, 1 automatic (thresholds from tools/gemm_ab.py: profiles/r02_gemm_ab_*.txt), 2 = 256-row
-    // tiles wherever >= 64 of them exist (else 128-row), 3 = 128-row tiles wherever >= 32 exist
-    if (pp_ok && pp != 3 && (blocks(256, 320) >= 200 || (pp == 2 && blocks(256, 320) >= 64))) {
+    // option gemm_pp: 0 never, 1 automatic (thresholds from tools/gemm_ab.py: profiles/r03_gemm_ab_b{1,2}.txt), 2 = 256-row
+    // tiles wherever >= 64 of them exist (else 128-row), 3 = 128-row tiles wherever >= 32 exist.
+    // Automatic: 256-row tiles from 192 of them (0.75 per CU: qkv 1280->3840 at B = 1, 47 instead of 60 us); 128-row
+    // tiles for the plain GEMMs with about ONE such tile per CU (the 640 / 1280-wide projections at M = 16 384 / 8 192 and
+    // ff2 at those sizes: 7-10 % over the tile kernels; the convolutions of that size stay on the tile kernels)
+    const long t128 = blocks(128, 320);
+    if (pp_ok && pp != 3 && (blocks(256, 320) >= 192 || (pp == 2 && blocks(256, 320) >= 64))) {
         rc = launch_pp(p, 256, stream);
-    } else if (pp_ok && pp >= 2 && blocks(128, 320) >= 32) {
+    } else if (pp_ok && ((pp >= 2 && t128 >= 32) || (pp == 1 && p.a_mode != 1 && t128 >= 240 && t128 <= 272))) {
         rc = launch_pp(p, 128, stream);
     } else if (force_tile() && wide) {
         p.ws = (float*)d->workspace;
