@@ -107,13 +107,16 @@ def load_new_concept(pipe, new_concept_embedding, enable_edlora=True):
     return pipe, new_concept_cfg
 
 
-def merge_lora_into_weight(original_state_dict, lora_state_dict, model_type, alpha):
-    """convert_edlora_to_diffusers.py:36-79: W += alpha * (up @ down) for every key that has LoRA factors."""
+def merge_lora_into_weight(original_state_dict, lora_state_dict, model_type, alpha, touched=None):
+    """convert_edlora_to_diffusers.py:36-79: W += alpha * (up @ down) for every key that has LoRA factors.  Same values as
+    the reference's result; the reference deep-copies the whole state dict first (2.5 GB for the UNet) — here the entries
+    without LoRA factors stay references to the caller's tensors, the merged ones are new tensors.  `touched` (a list)
+    receives the merged keys."""
     assert model_type in ('unet', 'text_encoder')
     keys = UNET_LORA_KEYS if model_type == 'unet' else TEXT_LORA_KEYS
-    merged = copy.deepcopy(original_state_dict)
+    merged = dict(original_state_dict)
     count = 0
-    for k in merged.keys():
+    for k in list(merged.keys()):
         down_name = k
         for suffix in keys:
             down_name = down_name.replace(suffix, suffix[:-len('weight')] + 'lora_down.weight')
@@ -129,21 +132,35 @@ def merge_lora_into_weight(original_state_dict, lora_state_dict, model_type, alp
         else:
             delta = up @ down
         merged[k] = w + alpha * delta.to(w.dtype)
+        if touched is not None:
+            touched.append(k)
     print(f'load {count} LoRAs of {model_type}')
     return merged
 
 
-def convert_edlora(pipe, state_dict, enable_edlora, alpha=0.6):
-    """convert_edlora_to_diffusers.py:82-105"""
+def convert_edlora(pipe, state_dict, enable_edlora, alpha=0.6, snapshot=None):
+    """convert_edlora_to_diffusers.py:82-105.  Only the weights that carry LoRA factors are written (the reference
+    reloads the whole merged state dict: same end state).  `snapshot` = {'unet': {}, 'text_encoder': {}} receives a copy of
+    every weight BEFORE it is modified (keys already present are kept: the first, pristine version), so that the caller
+    can undo the merge with `load_state_dict(snapshot[...], strict=False)` instead of keeping a deep copy of everything
+    (pipeline_videoswap.py:303-305,417-420 does the latter)."""
     state_dict = state_dict['params'] if 'params' in state_dict.keys() else state_dict
     new_concept_cfg = None
     if 'new_concept_embedding' in state_dict and len(state_dict['new_concept_embedding']) != 0:
         pipe, new_concept_cfg = load_new_concept(pipe, state_dict['new_concept_embedding'], enable_edlora)
+
+    def merge_into(model, lora, model_type):
+        current = model.state_dict()
+        touched = []
+        merged = merge_lora_into_weight(current, lora, model_type=model_type, alpha=alpha, touched=touched)
+        if snapshot is not None:
+            keep = snapshot.setdefault(model_type, {})
+            for k in touched:
+                if k not in keep:
+                    keep[k] = current[k].detach().clone()
+        model.load_state_dict({k: merged[k] for k in touched}, strict=False)
     if 'unet' in state_dict:
-        merged = merge_lora_into_weight(pipe.unet.state_dict(), state_dict['unet'], model_type='unet', alpha=alpha)
-        pipe.unet.load_state_dict(merged)
+        merge_into(pipe.unet, state_dict['unet'], 'unet')
     if 'text_encoder' in state_dict and pipe.text_encoder is not None and hasattr(pipe.text_encoder, 'state_dict'):
-        merged = merge_lora_into_weight(pipe.text_encoder.state_dict(), state_dict['text_encoder'],
-                                        model_type='text_encoder', alpha=alpha)
-        pipe.text_encoder.load_state_dict(merged)
+        merge_into(pipe.text_encoder, state_dict['text_encoder'], 'text_encoder')
     return pipe, new_concept_cfg
