@@ -6,7 +6,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R/tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/gemm_loop gemm_loop.hip || exit 1
 {
-for n in 128 256; do /tmp/gemm_loop $n 2560 160 1; done
+for n in 256; do /tmp/gemm_loop $n 2560 160 1; done
 echo "---- small panels (K = 320: A 164 KB per workgroup) ----"
 for n in 256; do /tmp/gemm_loop $n 320 160 1; done
 } > $O/${1:-r03f}_gemm_loop_sweep.txt 2>&1

@@ -157,7 +157,7 @@ void loop4(const half_t* __restrict__ A, const half_t* __restrict__ B, float* __
 // variant 8: the shipped ping-pong structure (8 waves of 64x160, a barrier per phase), same harness
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void loop8(const half_t* __restrict__ A, const half_t* __restrict__ B,
-                                             float* __restrict__ sink, int K, int nslab, int a_private, int b_private, int stagger) {
+                                             float* __restrict__ sink, int K, int nslab, int a_private, int b_private, int stagger, int a_every) {
     constexpr int TM = 2, TN = 5;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(512) void loop8(const half_t* __restrict__ A, const
         // different lines of a shared panel at any moment instead of all hitting the same L2 lines together)
         const unsigned koff = (unsigned)((slab + k_start) % (K / BKH)) * 128u;
         if (q < 4) {
+            if (slab % a_every) return;          // a_every = 3: the A panel is refreshed every third slab (conv with kw reuse)
             const int pc = wave * 4 + q;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(smem + slot + pc * 1024), 16, (pc & 1) ? v_o : v_e,
                                                      (int)(koff + (unsigned)(pc * 8) * ld2), 0, 0);
@@ -298,13 +299,20 @@ int main(int argc, char** argv) {
                     snprintf(name, sizeof(name), "8 waves ping-pong, A %s, B %s, K start + %d x wg", ap ? "private" : "shared ",
                              bp ? "private" : "shared ", st);
                     report(name, time_us([&] {
-                        hipLaunchKernelGGL(loop8, dim3(nwg), dim3(512), smem, 0, A, B, sink, K, nslab, ap, bp, st); }, 5));
+                        hipLaunchKernelGGL(loop8, dim3(nwg), dim3(512), smem, 0, A, B, sink, K, nslab, ap, bp, st, 1); }, 5));
                 }
+        for (int ae : {1, 3, 9})
+            for (int ap = 1; ap >= 0; --ap) {
+                char name[96];
+                snprintf(name, sizeof(name), "8 waves ping-pong, A %s refreshed every %d slab(s), B shared", ap ? "private" : "shared ", ae);
+                report(name, time_us([&] {
+                    hipLaunchKernelGGL(loop8, dim3(nwg), dim3(512), smem, 0, A, B, sink, K, nslab, ap, 0, 0, ae); }, 5));
+            }
         printf("status %s\n", hipGetErrorString(hipGetLastError()));
         return 0;
     }
     report("8 waves, ping-pong, barrier per phase", time_us([&] {
-        hipLaunchKernelGGL(loop8, dim3(nwg), dim3(512), smem, 0, A, B, sink, K, nslab, 1, 0, 0); }, 5));
+        hipLaunchKernelGGL(loop8, dim3(nwg), dim3(512), smem, 0, A, B, sink, K, nslab, 1, 0, 0, 1); }, 5));
 #define RUN4(TM, N0, N1)                                                                                                \
     {                                                                                                                   \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&loop4<TM, N0, N1>),                                    \
