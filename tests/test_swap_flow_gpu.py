@@ -14,7 +14,8 @@ pytestmark = pytest.mark.device
 
 SOURCE = 'a silver jeep driving down a curvy road in the countryside'
 STEPS, FRAMES = 4, 2
-HW = 64 if DEV == 'cuda' else 32     # 64x64 latents on the GPU: only the 16x16 / 8x8 layers are stored, as in the real model
+HW = 32     # (the real 64x64 / SD-1.5-width case, with the reference's own controllers on the oracle side, is
+            #  tests/test_cfg3_fullwidth_gpu.py; this one checks the orchestration of `validation` at tiny width)
 
 
 def synthetic_lora(state_dict, seed=4, rank=4):
