@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 5
+#define VSX_ABI_VERSION 6
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -271,7 +271,8 @@ int vsx_alltoall_f16(const void* send, void* recv, int64_t nouter, int64_t ninne
  *   vsx_geglu_bwd     dout [M, N], y2 [M, 2N] -> dy2 [M, 2N]
  *   vsx_silu_bwd      dx = dy * silu'(x)   (adapter MLP, adapter_model.py:12-22)
  *   vsx_groupnorm_bwd data gradient of vsx_groupnorm_apply (same arguments; statistics recomputed; dy [.., C1+C2]
- *                     -> dx1 [.., C1], dx2 [.., C2]); ws: nimg*groups*4 floats   (resnet.py:166-177)
+ *                     -> dx1 [.., C1], dx2 [.., C2]); ws: vsx_groupnorm_bwd_workspace(nimg, rows, groups) FLOATS
+ *                     (chunk partial sums of a two-level reduction, ABI 6)   (resnet.py:166-177)
  *   vsx_layernorm_bwd data gradient of vsx_layernorm (the positional encoding is added after the normalisation)
  *   vsx_softmax_bwd   dS = scale * P o (dP - rowsum(dP o P)) in place over dP, rows padded to ld
  *   vsx_sum_pool2x2   [n, 2h, 2w, c] -> [n, h, w, c]: gradient of the nearest-2x upsampling folded into a conv
@@ -280,6 +281,7 @@ int vsx_alltoall_f16(const void* send, void* recv, int64_t nouter, int64_t ninne
 int vsx_geglu_fwd(const void* y2, void* out, int64_t M, int64_t N, vsx_stream_t stream);
 int vsx_geglu_bwd(const void* dout, const void* y2, void* dy2, int64_t M, int64_t N, vsx_stream_t stream);
 int vsx_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, vsx_stream_t stream);
+int64_t vsx_groupnorm_bwd_workspace(int64_t nimg, int64_t rows, int64_t groups);
 int vsx_groupnorm_bwd(const void* dy, const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
                       int64_t C2, int64_t groups, const void* gamma, const void* beta, float eps, int64_t silu,
                       void* ws, void* dx1, void* dx2, vsx_stream_t stream);

@@ -80,7 +80,7 @@ int main() {
         auto x1 = randh(nimg * rows * C1, 1.5f, 0.3f), x2 = randh(nimg * rows * (C2 ? C2 : 1)), dy = randh(nimg * rows * C);
         auto gamma = randh(C, 0.3f, 1.0f), beta = randh(C, 0.2f);
         std::vector<half_t> dx1(nimg * rows * C1), dx2(nimg * rows * (C2 ? C2 : 1));
-        std::vector<float> ws(nimg * groups * 4);
+        std::vector<float> ws(vsx_groupnorm_bwd_workspace(nimg, rows, groups));
         vsx_groupnorm_bwd(dy.data(), x1.data(), C2 ? x2.data() : nullptr, nimg, rows, C1, C2, groups, gamma.data(),
                           beta.data(), eps, silu, ws.data(), dx1.data(), C2 ? dx2.data() : nullptr, nullptr);
         std::vector<double> w1(nimg * rows * C1), w2(nimg * rows * (C2 ? C2 : 1));

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.environ.get('VSX_LIB_VARIANT') or None
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so' if not VARIANT else f'libvsx_{VARIANT}.so')
 
-VSX_ABI_VERSION = 5
+VSX_ABI_VERSION = 6
 
 
 class VsxError(RuntimeError):
@@ -93,6 +93,7 @@ PROTOTYPES = {
     'vsx_geglu_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'vsx_geglu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'vsx_silu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'vsx_groupnorm_bwd_workspace': (c_int64, [c_int64, c_int64, c_int64]),
     'vsx_groupnorm_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                   c_void_p, c_float, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vsx_layernorm_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64, c_void_p]),

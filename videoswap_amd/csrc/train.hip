@@ -14,9 +14,7 @@
 // The matrix work of the backward pass (linear / conv dgrad, the attention products) runs on vsx_gemm_f16 with
 // transposed / flipped weight copies (videoswap_amd/autograd.py).  All kernels here are HBM-bound streaming passes:
 // 16-byte accesses, fp32 arithmetic and fp32 reductions in a fixed order (no atomics: results are deterministic).
-// First version: correctness first — the GroupNorm backward uses one workgroup per (image, group), which leaves most
-// CUs idle for the 5-D GroupNorm (64 workgroups); it gets the chunked two-level reduction of the forward once the
-// step has been measured.
+// The GroupNorm backward is a chunked two-level reduction like the forward (see below).
 #include "common.h"
 
 namespace {
@@ -85,76 +83,204 @@ __global__ void silu_bwd_kernel(const half_t* __restrict__ dy, const half_t* __r
     dx[i] = (half_t)((float)dy[i] * (s + xf * s * (1.0f - s)));
 }
 
-// GroupNorm backward, grid (groups, nimg).  Group g of image i covers channels [g*cpg, (g+1)*cpg) of all `rows`
-// rows; channels < C1 live in x1 / dx1, the others in x2 / dx2 (the skip concat).  Three passes over the group:
-// (1) mean / rstd, (2) s1 = sum(gz), s2 = sum(gz * xhat) with gz = dy * gamma (* silu'(z)), (3) dx.
-__global__ __launch_bounds__(TR_THREADS) void gn_bwd_kernel(const half_t* __restrict__ dy, const half_t* __restrict__ x1,
-                                                            const half_t* __restrict__ x2, long rows, int C1, int C2,
-                                                            int groups, const half_t* __restrict__ gamma,
-                                                            const half_t* __restrict__ beta, float eps, int silu,
-                                                            float* __restrict__ ws, half_t* __restrict__ dx1,
-                                                            half_t* __restrict__ dx2) {
-    __shared__ float red[TR_THREADS / 64];
+// ---------------------------------------------------------------------------------------------------------------------
+// GroupNorm backward as a chunked two-level reduction (the first version ran ONE workgroup per (image, group): 64
+// workgroups for the 5-D GroupNorm of a resnet, scalar loads, an integer division per element — 1.7 ms per call on average
+// and 36 % of the training step's kernel time, profiles/r03_train_kernel_stats.txt).  Group g of image i covers channels
+// [g*cpg, (g+1)*cpg) of all `rows` rows; channels < C1 live in x1 / dx1, the others in x2 / dx2 (the skip concat).
+//   pass 1  gnb_partial<0>: per (chunk of rows, image) the group sums of x and x^2             -> finalize: mean, rstd
+//   pass 2  gnb_partial<1>: per (chunk, image) the group sums of gz and gz * xhat,
+//                           gz = dy * gamma (* silu'(z))                                        -> finalize: m1, m2
+//   pass 3  gnb_apply:      dx = rstd * (gz - m1 - xhat * m2)
+// A thread owns one 16-byte vector of channels (the same one for every row it visits), so its group parameters live in
+// registers; rows are visited `rp` at a time by the workgroup, 16-byte loads and stores.  Deterministic: fixed-shape tree
+// per chunk, chunks summed in index order.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GNB_THREADS = 512;
+
+__host__ __device__ inline int gnb_chunk_rows(long rows, long nimg) {      // ~2048 workgroups whatever the split
+    long r = rows * nimg / 2048;
+    return (int)(r < 8 ? 8 : (r > 512 ? 512 : r));
+}
+
+__device__ __forceinline__ uint4 gnb_load(const half_t* x1, const half_t* x2, long row, int c, int C1, int C2) {
+    const half_t* ptr = (c < C1) ? x1 + row * C1 + c : x2 + row * C2 + (c - C1);
+    return ld16(ptr);
+}
+
+// gz of one element: the upstream gradient through gamma and (optionally) SiLU
+__device__ __forceinline__ float gnb_gz(float dyv, float xh, float ga, float be, int silu) {
+    if (silu) {
+        const float z = xh * ga + be;
+        const float sg = sigmoid_f(z);
+        dyv *= sg + z * sg * (1.0f - sg);
+    }
+    return dyv * ga;
+}
+
+// grid (nchunks, nimg).  WHAT 0: (sum x, sum x^2); WHAT 1: (sum gz, sum gz * xhat) — per group, into
+// partial[((img * nchunks + chunk) * groups + g) * 2 ..]
+template <int WHAT>
+__global__ __launch_bounds__(GNB_THREADS) void gnb_partial_kernel(const half_t* __restrict__ dy,
+                                                                  const half_t* __restrict__ x1,
+                                                                  const half_t* __restrict__ x2, long rows, int C1, int C2,
+                                                                  int groups, const half_t* __restrict__ gamma,
+                                                                  const half_t* __restrict__ beta, int silu,
+                                                                  const float* __restrict__ stats,
+                                                                  float* __restrict__ partial) {
+    __shared__ float red_a[4096];
+    __shared__ float red_b[4096];
     const int C = C1 + C2;
     const int cpg = C / groups;
+    const int vpr = C >> 3;
+    const int rp = GNB_THREADS / vpr;          // rows per pass (>= 1: C <= 4096)
+    const int tid = threadIdx.x;
+    const int rl = tid / vpr;
+    const int cv = tid - rl * vpr;
+    const long img = blockIdx.y;
+    const int rpc = gnb_chunk_rows(rows, gridDim.y);
+    const long r0 = (long)blockIdx.x * rpc;
+    const long r1 = min(r0 + (long)rpc, rows);
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; }
+    if (rl < rp) {
+        float mu[8], rs[8], ga[8], be[8];
+        if (WHAT == 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = cv * 8 + e;
+                const int g = c / cpg;
+                mu[e] = stats[(img * groups + g) * 2];
+                rs[e] = stats[(img * groups + g) * 2 + 1];
+                ga[e] = (float)gamma[c];
+                be[e] = (float)beta[c];
+            }
+        }
+        for (long r = r0 + rl; r < r1; r += rp) {
+            const h8 xv = as_h8(gnb_load(x1, x2, img * rows + r, cv * 8, C1, C2));
+            if (WHAT == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)xv[e];
+                    a[e] += f;
+                    b[e] += f * f;
+                }
+            } else {
+                const h8 dv = as_h8(ld16(dy + (img * rows + r) * C + cv * 8));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)xv[e] - mu[e]) * rs[e];
+                    const float gz = gnb_gz((float)dv[e], xh, ga[e], be[e], silu);
+                    a[e] += gz;
+                    b[e] += gz * xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red_a[rl * C + cv * 8 + e] = a[e];
+            red_b[rl * C + cv * 8 + e] = b[e];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += GNB_THREADS) {
+        float sa = 0.f, sb = 0.f;
+        for (int r = 0; r < rp; ++r) { sa += red_a[r * C + c]; sb += red_b[r * C + c]; }
+        red_a[c] = sa;
+        red_b[c] = sb;
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float sa = 0.f, sb = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { sa += red_a[c]; sb += red_b[c]; }
+        float* out = partial + ((img * gridDim.x + blockIdx.x) * groups + tid) * 2;
+        out[0] = sa;
+        out[1] = sb;
+    }
+}
+
+// grid (groups, nimg), block 256: chunk partials -> WHAT 0: (mean, rstd); WHAT 1: (mean of gz, mean of gz * xhat)
+template <int WHAT>
+__global__ __launch_bounds__(256) void gnb_finalize_kernel(const float* __restrict__ partial, int nchunks, int groups,
+                                                           float inv_count, float eps, float* __restrict__ out) {
+    __shared__ float s_a[256];
+    __shared__ float s_b[256];
+    const int tid = threadIdx.x;
     const int g = blockIdx.x;
     const long img = blockIdx.y;
-    const int c0 = g * cpg;
-    const long n = rows * cpg;
-    const long base_row = img * rows;
+    const float* pp = partial + (img * nchunks * groups + g) * 2;
+    float a = 0.f, b = 0.f;
+    for (int ch = tid; ch < nchunks; ch += 256) {
+        a += pp[(long)ch * groups * 2];
+        b += pp[(long)ch * groups * 2 + 1];
+    }
+    s_a[tid] = a;
+    s_b[tid] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) { s_a[tid] += s_a[tid + w]; s_b[tid] += s_b[tid + w]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float* o = out + (img * groups + g) * 2;
+        if (WHAT == 0) {
+            const float mean = s_a[0] * inv_count;
+            o[0] = mean;
+            o[1] = rsqrtf(fmaxf(s_b[0] * inv_count - mean * mean, 0.f) + eps);
+        } else {
+            o[0] = s_a[0] * inv_count;
+            o[1] = s_b[0] * inv_count;
+        }
+    }
+}
 
-    auto xat = [&](long r, int c) -> float {
-        return c < C1 ? (float)x1[(base_row + r) * C1 + c] : (float)x2[(base_row + r) * C2 + (c - C1)];
-    };
-    // (1) statistics (fp32, two-pass variance: the inputs are fp16, the group has up to ~10^6 elements)
-    float s = 0.f;
-    for (long i = threadIdx.x; i < n; i += TR_THREADS) s += xat(i / cpg, c0 + (int)(i % cpg));
-    const float mean = block_sum(s, red) / (float)n;
-    float q = 0.f;
-    for (long i = threadIdx.x; i < n; i += TR_THREADS) {
-        const float d = xat(i / cpg, c0 + (int)(i % cpg)) - mean;
-        q += d * d;
+// grid (nchunks, nimg): dx = rstd * (gz - m1 - xhat * m2)
+__global__ __launch_bounds__(GNB_THREADS) void gnb_apply_kernel(const half_t* __restrict__ dy, const half_t* __restrict__ x1,
+                                                                const half_t* __restrict__ x2, long rows, int C1, int C2,
+                                                                int groups, const half_t* __restrict__ gamma,
+                                                                const half_t* __restrict__ beta, int silu,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ sums, half_t* __restrict__ dx1,
+                                                                half_t* __restrict__ dx2) {
+    const int C = C1 + C2;
+    const int cpg = C / groups;
+    const int vpr = C >> 3;
+    const int rp = GNB_THREADS / vpr;
+    const int tid = threadIdx.x;
+    const int rl = tid / vpr;
+    const int cv = tid - rl * vpr;
+    if (rl >= rp) return;
+    const long img = blockIdx.y;
+    const int rpc = gnb_chunk_rows(rows, gridDim.y);
+    const long r0 = (long)blockIdx.x * rpc;
+    const long r1 = min(r0 + (long)rpc, rows);
+    float mu[8], rs[8], ga[8], be[8], m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cv * 8 + e;
+        const int g = c / cpg;
+        mu[e] = stats[(img * groups + g) * 2];
+        rs[e] = stats[(img * groups + g) * 2 + 1];
+        m1[e] = sums[(img * groups + g) * 2];
+        m2[e] = sums[(img * groups + g) * 2 + 1];
+        ga[e] = (float)gamma[c];
+        be[e] = (float)beta[c];
     }
-    const float rstd = rsqrtf(block_sum(q, red) / (float)n + eps);
-    // (2) the two reductions of the upstream gradient
-    float s1 = 0.f, s2 = 0.f;
-    for (long i = threadIdx.x; i < n; i += TR_THREADS) {
-        const long r = i / cpg;
-        const int c = c0 + (int)(i % cpg);
-        const float xh = (xat(r, c) - mean) * rstd;
-        const float ga = (float)gamma[c];
-        float gz = (float)dy[(base_row + r) * C + c];
-        if (silu) {
-            const float z = xh * ga + (float)beta[c];
-            const float sg = sigmoid_f(z);
-            gz *= sg + z * sg * (1.0f - sg);
+    const int c0 = cv * 8;
+    for (long r = r0 + rl; r < r1; r += rp) {
+        const long row = img * rows + r;
+        const h8 xv = as_h8(gnb_load(x1, x2, row, c0, C1, C2));
+        const h8 dv = as_h8(ld16(dy + row * C + c0));
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)xv[e] - mu[e]) * rs[e];
+            const float gz = gnb_gz((float)dv[e], xh, ga[e], be[e], silu);
+            o[e] = (half_t)(rs[e] * (gz - m1[e] - xh * m2[e]));
         }
-        gz *= ga;
-        s1 += gz;
-        s2 += gz * xh;
-    }
-    const float m1 = block_sum(s1, red) / (float)n;
-    const float m2 = block_sum(s2, red) / (float)n;
-    if (threadIdx.x == 0) {
-        float* w = ws + (img * groups + g) * 4;
-        w[0] = mean; w[1] = rstd; w[2] = m1; w[3] = m2;
-    }
-    // (3) dx = rstd * (gz - mean(gz) - xhat * mean(gz * xhat))
-    for (long i = threadIdx.x; i < n; i += TR_THREADS) {
-        const long r = i / cpg;
-        const int c = c0 + (int)(i % cpg);
-        const float xh = (xat(r, c) - mean) * rstd;
-        const float ga = (float)gamma[c];
-        float gz = (float)dy[(base_row + r) * C + c];
-        if (silu) {
-            const float z = xh * ga + (float)beta[c];
-            const float sg = sigmoid_f(z);
-            gz *= sg + z * sg * (1.0f - sg);
-        }
-        gz *= ga;
-        const half_t o = (half_t)(rstd * (gz - m1 - xh * m2));
-        if (c < C1) dx1[(base_row + r) * C1 + c] = o;
-        else dx2[(base_row + r) * C2 + (c - C1)] = o;
+        if (c0 < C1) st16(dx1 + row * C1 + c0, as_u4(o));
+        else st16(dx2 + row * C2 + (c0 - C1), as_u4(o));
     }
 }
 
@@ -294,17 +420,48 @@ extern "C" int vsx_silu_bwd(const void* dy, const void* x, void* dx, int64_t n, 
     return vsx_check_launch("vsx_silu_bwd");
 }
 
+extern "C" int64_t vsx_groupnorm_bwd_workspace(int64_t nimg, int64_t rows, int64_t groups) {
+    if (nimg <= 0 || rows <= 0 || groups <= 0) return 0;
+    const int rpc = gnb_chunk_rows(rows, nimg);
+    const int64_t nchunks = (rows + rpc - 1) / rpc;
+    return nimg * groups * (4 + 2 * nchunks);            // floats: stats | sums | chunk partials (reused by both passes)
+}
+
 extern "C" int vsx_groupnorm_bwd(const void* dy, const void* x1, const void* x2, int64_t nimg, int64_t rows, int64_t C1,
                                  int64_t C2, int64_t groups, const void* gamma, const void* beta, float eps,
                                  int64_t silu, void* ws, void* dx1, void* dx2, vsx_stream_t stream) {
     VSX_REQUIRE(dy && x1 && gamma && beta && ws && dx1 && (C2 == 0 || (x2 && dx2)), VSX_E_BADSHAPE,
                 "groupnorm_bwd: null argument");
-    VSX_REQUIRE(nimg > 0 && rows > 0 && C1 > 0 && C2 >= 0 && groups > 0 && (C1 + C2) % groups == 0 && nimg <= 65535,
+    const int64_t C = C1 + C2;
+    VSX_REQUIRE(nimg > 0 && rows > 0 && C1 > 0 && C2 >= 0 && groups > 0 && groups <= 256 && C % groups == 0 &&
+                    nimg <= 65535,
                 VSX_E_BADSHAPE, "groupnorm_bwd: bad sizes");
-    hipLaunchKernelGGL(gn_bwd_kernel, dim3((unsigned)groups, (unsigned)nimg), dim3(TR_THREADS), 0, (hipStream_t)stream,
-                       (const half_t*)dy, (const half_t*)x1, (const half_t*)x2, (long)rows, (int)C1, (int)C2,
-                       (int)groups, (const half_t*)gamma, (const half_t*)beta, eps, (int)silu, (float*)ws,
-                       (half_t*)dx1, (half_t*)dx2);
+    VSX_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C <= 4096, VSX_E_UNSUPPORTED,
+                "groupnorm_bwd: channel counts must be multiples of 8 and C1 + C2 <= 4096 (C1=%ld C2=%ld)", (long)C1, (long)C2);
+    VSX_REQUIRE(vsx_aligned16(dy) && vsx_aligned16(x1) && vsx_aligned16(x2) && vsx_aligned16(dx1) && vsx_aligned16(dx2),
+                VSX_E_BADSHAPE, "groupnorm_bwd: tensors must be 16-byte aligned");
+    const int rpc = gnb_chunk_rows(rows, nimg);
+    const int nchunks = (int)((rows + rpc - 1) / rpc);
+    float* stats = (float*)ws;
+    float* sums = stats + nimg * groups * 2;
+    float* partial = sums + nimg * groups * 2;
+    const float inv_count = 1.0f / ((float)rows * (float)(C / groups));
+    const dim3 gchunks((unsigned)nchunks, (unsigned)nimg), ggroups((unsigned)groups, (unsigned)nimg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gnb_partial_kernel<0>, gchunks, dim3(GNB_THREADS), 0, st, (const half_t*)dy, (const half_t*)x1,
+                       (const half_t*)x2, (long)rows, (int)C1, (int)C2, (int)groups, (const half_t*)gamma,
+                       (const half_t*)beta, (int)silu, (const float*)stats, partial);
+    hipLaunchKernelGGL(gnb_finalize_kernel<0>, ggroups, dim3(256), 0, st, (const float*)partial, nchunks, (int)groups,
+                       inv_count, eps, stats);
+    hipLaunchKernelGGL(gnb_partial_kernel<1>, gchunks, dim3(GNB_THREADS), 0, st, (const half_t*)dy, (const half_t*)x1,
+                       (const half_t*)x2, (long)rows, (int)C1, (int)C2, (int)groups, (const half_t*)gamma,
+                       (const half_t*)beta, (int)silu, (const float*)stats, partial);
+    hipLaunchKernelGGL(gnb_finalize_kernel<1>, ggroups, dim3(256), 0, st, (const float*)partial, nchunks, (int)groups,
+                       inv_count, eps, sums);
+    hipLaunchKernelGGL(gnb_apply_kernel, gchunks, dim3(GNB_THREADS), 0, st, (const half_t*)dy, (const half_t*)x1,
+                       (const half_t*)x2, (long)rows, (int)C1, (int)C2, (int)groups, (const half_t*)gamma,
+                       (const half_t*)beta, (int)silu, (const float*)stats, (const float*)sums, (half_t*)dx1,
+                       (half_t*)dx2);
     return vsx_check_launch("vsx_groupnorm_bwd");
 }
 

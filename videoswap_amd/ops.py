@@ -554,7 +554,7 @@ def group_norm_bwd(dy, x, gamma, beta, groups, eps, nimg, silu=False, x2=None):
     rows = x.numel() // C1 // nimg
     dx = torch.empty_like(x)
     dx2 = torch.empty_like(x2) if x2 is not None else None
-    ws = torch.empty(nimg, groups, 4, dtype=torch.float32, device=x.device)
+    ws = torch.empty(int(_train_fn('vsx_groupnorm_bwd_workspace')(nimg, rows, groups)), dtype=torch.float32, device=x.device)
     check(_train_fn('vsx_groupnorm_bwd')(_p(dy), _p(x), _p(x2), nimg, rows, C1, C2, groups, _p(gamma), _p(beta),
                                          float(eps), 1 if silu else 0, _p(ws), _p(dx), _p(dx2), _stream()),
           'vsx_groupnorm_bwd')
