@@ -141,6 +141,32 @@ def test_forward_56x96(models):
     _check('unet_B2_T4_56x96', _fwd(prod, x, 501, txt), _fwd(ora_dev, x, 501, txt), _fwd(ora_h, x, 501, txt))
 
 
+def test_forward_24_frames(models):
+    """(3b) T = 24: the longest clip the reference's positional-encoding table allows (motion_module.py:237-255,
+    `temporal_position_encoding_max_len: 24`); 24 query x 24 key frames per site in the temporal attention kernel."""
+    cfg, ora, ora_dev, ora_h, prod = models
+    x, txt = _inputs(1, 24, 64, 64, seed=124)
+    _check('unet_B1_T24_64x64', _fwd(prod, x, 261, txt), _fwd(ora_dev, x, 261, txt), _fwd(ora_h, x, 261, txt))
+
+
+def test_sequential_steps_448x768(models):
+    """(5b) the loops at the size of 26 of the 30 reference option files (448 x 768 frames = 56 x 96 latents), T = 8,
+    3 + 3 steps: ragged row tiles (M = 43 008 / 86 016) and N = 5 376 keys in every UNet call of both loops."""
+    cfg, ora, ora_dev, ora_h, prod = models
+    x, txt = _inputs(1, 8, 56, 96, seed=125)
+    neg = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(8))
+    inv_ref, out_ref = _oracle_loops(ora_dev, x, txt, neg, 3)
+    inv_h, out_h = _oracle_loops(ora_h, x, txt, neg, 3)
+    inv_p, out_p = _product_loops(prod, x, txt, neg, 3)
+    e_inv, e16_inv = rel_l2(inv_p, inv_ref), rel_l2(inv_h, inv_ref)
+    e_out, e16_out = rel_l2(out_p, out_ref), rel_l2(out_h, out_ref)
+    _record('loops_3+3_T8_56x96', inversion_rel_l2=e_inv, inversion_rel_l2_fp16_oracle=e16_inv, final_rel_l2=e_out,
+            final_rel_l2_fp16_oracle=e16_out, final_cosine=cosine(out_p, out_ref))
+    assert torch.isfinite(out_p).all()
+    assert e_inv <= 2 * e16_inv + 1e-4, f'inversion drift {e_inv:.3e} vs fp16-storage oracle {e16_inv:.3e}'
+    assert e_out <= 2 * e16_out + 1e-4, f'final-latent drift {e_out:.3e} vs fp16-storage oracle {e16_out:.3e}'
+
+
 def test_forward_edlora_text_and_adapter_residuals(models):
     """(4) config 3's inputs at full width: per-layer text embeddings [B,16,77,768] and the four adapter residuals."""
     from oracle import pipeline as opipe
