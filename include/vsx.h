@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 6
+#define VSX_ABI_VERSION 7
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -104,6 +104,14 @@ typedef struct vsx_gemm_desc {
        pair (-1, -1) selects the symmetric ks/2 of nn.Conv2d(padding=ks//2).  diffusers' VAE encoder downsamples with
        F.pad(x, (0, 1, 0, 1)) + a stride-2 conv without padding = (pad_lo, pad_hi) = (0, 1). */
     int64_t pad_lo, pad_hi;
+    /* ABI v7: LayerNorm folded into the Linear that consumes it (attention.py:182,199,205 norm1/2/3 -> to_q/k/v, GEGLU;
+       motion_module.py:213,219).  With W' = W o gamma as the B operand and A = the RAW activation,
+           LN(x) W^T + b  =  rstd_m * acc[m,n]  -  rstd_m * mean_m * c1[n]  +  (beta W^T + b)[n]
+       rowscale = fp32 [M][2] = (rstd_m, -rstd_m * mean_m) (vsx_row_stats), colvec = fp32 [N] (geglu: [2N]) = c1[n] =
+       sum_k W'[n,k]; the last term is passed as `bias`, the temporal positional encoding pe W^T as `rowvec`.  The
+       normalised tensor is never written or re-read.  Plain (a_mode 0), unbatched GEMMs only; NULL / NULL = off. */
+    const void* rowscale;
+    const void* colvec;
 } vsx_gemm_desc;
 
 int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream);
@@ -130,6 +138,10 @@ int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg, int64_t ro
                         int64_t C2, int64_t groups, const float* partial, int64_t nchunks,
                         int64_t count_rows, const void* gamma, const void* beta, float eps,
                         int64_t silu, float* stats, void* y, vsx_stream_t stream);
+
+/* Row statistics of x[M, C] for a LayerNorm folded into its consumer GEMM (vsx_gemm_desc.rowscale):
+ * stats[m] = (rstd_m, -rstd_m * mean_m), rstd = 1/sqrt(var + eps), fp32 statistics as in vsx_layernorm. */
+int vsx_row_stats(const void* x, int64_t M, int64_t C, float eps, float* stats, vsx_stream_t stream);
 
 /* K4: LayerNorm over the last dim of x[M, C] (attention.py:182,199,205; motion_module.py:213,219).
  * If pe != NULL, adds pe[((m / rows_per_frame) % frames) + frame_offset][c] (fp16 [max_len, C]) to

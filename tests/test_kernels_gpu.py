@@ -331,6 +331,74 @@ def test_layer_norm_pe():
 
 
 # --------------------------------------------------------------------------------------------
+# LayerNorm folded into the consuming GEMM (vsx_gemm_desc.rowscale / colvec, ops.DeferredLN): every epilogue that can
+# receive it — persistent staged rows (plain, GEGLU), tile kernels (16-byte stores, GEGLU, generic), the transposed V^T
+# store, the split-K combine — against LayerNorm -> Linear in fp32
+# --------------------------------------------------------------------------------------------
+def _ln_inputs(M, K, seed):
+    # rows with very different means and scales: the identity subtracts rstd * mean * sum_k W'
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, K, generator=g) * (0.5 + 3 * torch.rand(M, 1, generator=g)) + 4 * torch.randn(M, 1, generator=g)
+    return x.half().to(DEV), rnd(K, seed=seed + 1) * 0.3 + 1, rnd(K, seed=seed + 2) * 0.2
+
+
+@pytest.mark.parametrize('M,K,N,geglu,res,pe', [
+    (65536, 320, 960, False, False, True),     # persistent 256-row tiles, temporal qkv with the positional encoding
+    (65536, 320, 320, False, True, False),     # persistent, residual
+    (32768, 320, 1280, True, False, False),    # persistent GEGLU
+    (8192, 1280, 1280, False, True, False),    # 128-row persistent tiles
+    (4096, 640, 640, False, False, False),     # tile kernel, 16-byte stores
+    (1000, 1280, 5120, True, False, False),    # tile kernel GEGLU, ragged M
+    (1024, 1280, 3840, False, False, False),   # split-K combine
+    (77, 768, 320, False, False, False),       # 64x64 tiles, ragged
+])
+def test_layer_norm_folded_into_linear(M, K, N, geglu, res, pe):
+    o = ops()
+    x, gamma, beta = _ln_inputs(M, K, seed=40)
+    w, b = rnd((2 * N if geglu else N), K, seed=43, scale=K ** -0.5), rnd((2 * N if geglu else N), seed=44)
+    r = rnd(M, N, seed=45) if res else None
+    frames, hw = 4, M // 8 if pe else 0
+    table = rnd(24, K, seed=46) if pe else None
+    ln = o.DeferredLN(x, gamma, beta, 1e-5, table, hw, frames, 2 if pe else 0)
+    out = o.linear(ln, w, b, residual=r, geglu=geglu)
+    y = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)
+    if pe:
+        y = (y.view(-1, frames, hw, K) + table.float()[2:2 + frames][None, :, None, :]).view(M, K)
+    ref = y @ w.float().t() + b.float()
+    if geglu:
+        ref = ref[:, :N] * F.gelu(ref[:, N:])
+    if res:
+        ref = ref + r.float()
+    assert rel_err(out, ref) < 2e-3
+    # the same call through the materialised LayerNorm (what VSX_LN_FUSE=0 runs) agrees to fp16 noise
+    plain = o.linear(ln.materialize(), w, b, residual=r, geglu=geglu)
+    assert rel_err(out, plain.float(), l2_tol=2e-3, row_tol=1e-2) < 4e-3
+
+
+@pytest.mark.parametrize('nimg,rows,K,N', [(16, 4096, 320, 320), (32, 256, 1280, 1280), (3, 77, 768, 640)])
+def test_layer_norm_folded_into_the_transposed_v_projection(nimg, rows, K, N):
+    o = ops()
+    x, gamma, beta = _ln_inputs(nimg * rows, K, seed=50)
+    w, b = rnd(N, K, seed=53, scale=K ** -0.5), rnd(N, seed=54)
+    ln = o.DeferredLN(x, gamma, beta, 1e-5)
+    vt = o.linear_vt(ln, w, b, rows)
+    y = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5) @ w.float().t() + b.float()
+    ref = y.view(nimg, rows, N).transpose(1, 2)
+    assert rel_err(vt[:, :, :rows], ref) < 2e-3
+
+
+def test_row_stats_are_computed_once_per_deferred_layer_norm():
+    o = ops()
+    x, gamma, beta = _ln_inputs(2048, 320, seed=60)
+    ln = o.DeferredLN(x.view(2, 1024, 320), gamma, beta, 1e-5)
+    st = ln.stats()
+    assert ln.reshape(2048, 320).stats() is st and ln.view(2048, 320).stats() is st
+    mean, var = x.float().mean(1), x.float().var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    assert torch.allclose(st[:, 0], rstd, rtol=1e-4) and torch.allclose(st[:, 1], -rstd * mean, rtol=1e-4, atol=1e-5)
+
+
+# --------------------------------------------------------------------------------------------
 # attention
 # --------------------------------------------------------------------------------------------
 def attn_ref(q, k, v, heads, scale, kv_div=1):

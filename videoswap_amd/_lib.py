@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.environ.get('VSX_LIB_VARIANT') or None
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so' if not VARIANT else f'libvsx_{VARIANT}.so')
 
-VSX_ABI_VERSION = 6
+VSX_ABI_VERSION = 7
 
 
 class VsxError(RuntimeError):
@@ -45,6 +45,7 @@ class GemmDesc(Structure):
         ('geglu', c_int64), ('alpha', c_double),
         ('workspace', c_void_p), ('workspace_bytes', c_int64),
         ('pad_lo', c_int64), ('pad_hi', c_int64),
+        ('rowscale', c_void_p), ('colvec', c_void_p),
     ]
 
 
@@ -61,6 +62,7 @@ PROTOTYPES = {
                                     c_void_p]),
     'vsx_groupnorm_apply': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                     c_int64, c_int64, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
+    'vsx_row_stats': (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p]),
     'vsx_layernorm': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
                               c_int64, c_void_p, c_void_p]),
     'vsx_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 14 + [c_float, c_void_p]),

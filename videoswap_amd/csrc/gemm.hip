@@ -522,6 +522,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             half_t* crow = Cb + (unsigned)m * (unsigned)ldc;
             const half_t* rrow = Rb ? Rb + (unsigned)m * (unsigned)ldr : nullptr;
             const half_t* rv = p.rowvec ? p.rowvec + ((unsigned)m / (unsigned)p.rows_per_vec) * (unsigned)Ni : nullptr;
+            // LayerNorm folded into the GEMM: out = rs * acc + rt * c1[n] (then bias / row vector / residual as usual)
+            const float* cvp = p.rowscale ? p.colvec : nullptr;
+            const float rs = cvp ? p.rowscale[2 * (unsigned)m] : 1.f, rt = cvp ? p.rowscale[2 * (unsigned)m + 1] : 0.f;
             if (p.geglu) {
                 // tile j: registers 0-7 are h of 16 output columns, registers 8-15 the matching g
 #pragma unroll
@@ -535,6 +538,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         for (int e = 0; e < 4; ++e) {
                             hv[e] = acc[j][i][4 * q + e] * p.alpha;
                             gv[e] = acc[j][i][8 + 4 * q + e] * p.alpha;
+                        }
+                        if (cvp) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (nb + e < Ni) {
+                                    hv[e] = __builtin_fmaf(rs, hv[e], rt * cvp[nb + e]);
+                                    gv[e] = __builtin_fmaf(rs, gv[e], rt * cvp[Ni + nb + e]);
+                                }
+                            }
                         }
                         if (p.vec4 && nb + 3 < Ni) {
                             if (p.bias) {
@@ -606,6 +618,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         float o[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = acc[j][i][4 * g + e] * p.alpha;
+                        if (cvp) {
+                            const f4v c = *reinterpret_cast<const f4v*>(cvp + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(rs, o[e], rt * c[e]);
+                        }
                         if (p.bias) {
                             const h4 b = *reinterpret_cast<const h4*>(p.bias + nb);
 #pragma unroll
@@ -651,6 +668,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                     float o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = acc[j][i][4 * g + e] * p.alpha;
+                    if (cvp) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nb + e < Ni) o[e] = __builtin_fmaf(rs, o[e], rt * cvp[nb + e]);
+                    }
                     if (p.vec4 && nb + 3 < Ni) {
                         if (p.bias) {
                             const h4 b = *reinterpret_cast<const h4*>(p.bias + nb);
@@ -698,6 +720,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             const int n = nb0 + wc * WN + j * 32 + l31;
             if (n >= Ni) continue;
             const float bv = p.bias ? (float)p.bias[n] : 0.f;
+            const float cvn = p.rowscale ? p.colvec[n] : 0.f;
             half_t* ccol = Cb + (long)n * p.ldc;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -707,7 +730,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                     if (mg >= Mi) continue;
                     float o[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[i][j][4 * g + e] * p.alpha + bv;
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * g + e] * p.alpha;
+                        if (p.rowscale) {
+                            const unsigned mr = (unsigned)min(mg + e, Mi - 1);
+                            v = __builtin_fmaf(p.rowscale[2 * mr], v, p.rowscale[2 * mr + 1] * cvn);
+                        }
+                        o[e] = v + bv;
+                    }
                     if (p.c_pack4 && mg + 3 < Mi) {
                         const unsigned img = (unsigned)mg / rpi;
                         const unsigned mm = (unsigned)mg - img * rpi;
@@ -744,6 +774,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
         const f4v v = *reinterpret_cast<const f4v*>(p.ws + z * slab + (size_t)m * p.N + nb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+    if (p.rowscale) {
+        const float rs = p.rowscale[2 * (size_t)m], rt = p.rowscale[2 * (size_t)m + 1];
+        const f4v c = *reinterpret_cast<const f4v*>(p.colvec + nb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(rs, acc[e], rt * c[e]);
     }
     if (p.bias) {
         const h4 b = *reinterpret_cast<const h4*>(p.bias + nb);
@@ -933,6 +969,11 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     p.bias = (const half_t*)d->bias;
     p.rowvec = (const half_t*)d->rowvec;
     p.residual = (const half_t*)d->residual;
+    p.rowscale = (const float*)d->rowscale;
+    p.colvec = (const float*)d->colvec;
+    VSX_REQUIRE((d->rowscale == nullptr) == (d->colvec == nullptr), VSX_E_BADSHAPE, "gemm: rowscale and colvec come together");
+    VSX_REQUIRE(!d->rowscale || (d->batch0 * d->batch1 == 1 && d->a_mode == 0 && vsx_aligned16(d->colvec)), VSX_E_UNSUPPORTED,
+                "gemm: rowscale / colvec (LayerNorm folded into a Linear) need an unbatched plain GEMM and a 16-byte aligned colvec");
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
     p.a_bs0 = d->a_bs0; p.a_bs1 = d->a_bs1; p.b_bs0 = d->b_bs0; p.b_bs1 = d->b_bs1;

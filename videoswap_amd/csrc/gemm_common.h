@@ -15,6 +15,9 @@ struct GemmParams {
     const half_t* bias;
     const half_t* rowvec;
     const half_t* residual;
+    // LayerNorm folded into the GEMM (vsx.h: rowscale / colvec): out = rs[m] * acc + rt[m] * c1[n] (+ bias ...)
+    const float* rowscale;      // [M][2] = (rstd, -rstd * mean) of the A rows, or nullptr
+    const float* colvec;        // [N] (geglu: [2N]) = sum_k B[n][k]
     long M, N, K;
     long lda, ldb, ldc, ldr;
     long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, r_bs0, r_bs1;

@@ -106,6 +106,15 @@ __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, con
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = (float)b[e];
     }
+    const float* rsp = add_bias ? p->rowscale : nullptr;         // LayerNorm identity (plain path: applied here)
+    float cv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cv[e] = 0.f;
+    if (rsp) {
+        const f4v c0 = *reinterpret_cast<const f4v*>(p->colvec + n), c1 = *reinterpret_cast<const f4v*>(p->colvec + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cv[e] = c0[e]; cv[e + 4] = c1[e]; }
+    }
     const half_t* rvp = p->rowvec;
     const half_t* resp = p->residual;
     half_t* cp = p->C;
@@ -118,6 +127,11 @@ __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, con
         const f4v a = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8);
         const f4v b = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8 + 4);
         float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (rsp) {
+            const float rs = rsp[2 * (unsigned)m], rt = rsp[2 * (unsigned)m + 1];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(rs, o[e], rt * cv[e]);
+        }
         if (add_bias && p->bias) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += bv[e];
@@ -153,6 +167,14 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
             // needs the bias first) is computed in the fragment layout; chunks: j = 0..3 (64 columns), j = 4 (16)
             const half_t* bias = p->bias;
             const int Ni = (int)p->N;
+            const float* rsp = p->rowscale;
+            const float* cvp = p->colvec;
+            float rs = 1.f, rt = 0.f;
+            if (rsp) {
+                const unsigned mr = (unsigned)min(mblk + l31, (int)p->M - 1);
+                rs = rsp[2 * mr];
+                rt = rsp[2 * mr + 1];
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int j0 = c * 4, nj = c ? 1 : 4;
@@ -168,6 +190,15 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
                         for (int e = 0; e < 4; ++e) {
                             hv[e] = acc[j][i][4 * q + e] * alpha;
                             gv[e] = acc[j][i][8 + 4 * q + e] * alpha;
+                        }
+                        if (rsp) {
+                            const f4v ch = *reinterpret_cast<const f4v*>(cvp + nb);
+                            const f4v cg = *reinterpret_cast<const f4v*>(cvp + Ni + nb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                hv[e] = __builtin_fmaf(rs, hv[e], rt * ch[e]);
+                                gv[e] = __builtin_fmaf(rs, gv[e], rt * cg[e]);
+                            }
                         }
                         if (bias) {
                             const h4 bh = *reinterpret_cast<const h4*>(bias + nb);
@@ -558,7 +589,7 @@ bool pp_supported(const GemmParams& p) {
     const long cols = p.geglu ? 2 * p.N : p.N;
     if (cols % 320 != 0 || p.c_mode != 0 || p.splitk > 1) return false;
     if (!p.vec8 || (p.residual && !p.rvec8)) return false;
-    if (!vsx_aligned16(p.bias) || !vsx_aligned16(p.rowvec)) return false;      // 16-byte epilogue loads
+    if (!vsx_aligned16(p.bias) || !vsx_aligned16(p.rowvec) || !vsx_aligned16(p.colvec)) return false;      // 16-byte epilogue loads
     if (p.geglu && p.rowvec) return false;
     if (p.a_mode == 1) {
         const int ctot = p.C1 + p.C2;

@@ -274,6 +274,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     }
 }
 
+// Row statistics only (LayerNorm folded into its consumer GEMM): same loads and the same fp32 arithmetic as
+// layernorm_kernel, no normalised output — stats[m] = (rstd, -rstd * mean).
+template <int NV, int R>
+__global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict__ x, long M, int C, float eps,
+                                                        float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (m0 >= M) return;
+    const int vpr = C >> 3;
+    uint4 raw[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int v = lane + 64 * k;
+            raw[r][k] = (v < vpr && m0 + r < M) ? ld16(x + (m0 + r) * C + v * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long m = m0 + r;
+        if (m >= M) break;
+        float f[NV][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const h8 h = as_h8(raw[r][k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { f[k][e] = (float)h[e]; sum += f[k][e]; }
+        }
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (lane + 64 * k < vpr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[k][e] - mean; sq += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+        if (lane == 0) {
+            stats[2 * m] = rstd;
+            stats[2 * m + 1] = -rstd * mean;
+        }
+    }
+}
+
 // in-place row softmax, one wave per row (fp16 storage, fp32 math).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ S, long nrows, int ncols, long ld) {
     const int lane = threadIdx.x & 63;
@@ -385,6 +431,22 @@ extern "C" int vsx_layernorm(const void* x, int64_t M, int64_t C, const void* ga
     else VSX_LN_LAUNCH(4, 1);
 #undef VSX_LN_LAUNCH
     return vsx_check_launch("vsx_layernorm");
+}
+
+extern "C" int vsx_row_stats(const void* x, int64_t M, int64_t C, float eps, float* stats, vsx_stream_t stream) {
+    VSX_REQUIRE(x && stats, VSX_E_BADSHAPE, "row_stats: null argument");
+    if (M == 0) return VSX_OK;
+    VSX_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, VSX_E_BADSHAPE, "row_stats: C=%ld must be a multiple of 8, <= 2048",
+                (long)C);
+    VSX_REQUIRE(vsx_aligned16(x), VSX_E_BADSHAPE, "row_stats: x must be 16-byte aligned");
+#define VSX_RS_LAUNCH(NV, R)                                                                                            \
+    hipLaunchKernelGGL((row_stats_kernel<NV, R>), dim3((unsigned)((M + 4 * (R) - 1) / (4 * (R)))), dim3(256), 0,            \
+                       (hipStream_t)stream, (const half_t*)x, (long)M, (int)C, eps, stats)
+    if (C <= 512) VSX_RS_LAUNCH(1, 4);
+    else if (C <= 1024) VSX_RS_LAUNCH(2, 2);
+    else VSX_RS_LAUNCH(4, 1);
+#undef VSX_RS_LAUNCH
+    return vsx_check_launch("vsx_row_stats");
 }
 
 extern "C" int vsx_softmax_rows(void* S, int64_t nrows, int64_t ncols, int64_t ld, vsx_stream_t stream) {

@@ -118,7 +118,17 @@ class GroupNorm(nn.GroupNorm):
 
 
 class LayerNorm(nn.LayerNorm):
-    def forward(self, x, pe=None, rows_per_frame=0, frames=0, frame_offset=0):
+    def forward(self, x, pe=None, rows_per_frame=0, frames=0, frame_offset=0, defer=False):
+        """`defer=True` (the caller knows that every consumer is a Linear of this package: native attention processors,
+        FeedForward) returns an `ops.DeferredLN`: the normalisation is folded into the consuming GEMMs and the normalised
+        tensor is never written.  Inference on the GPU only (the gradient path and the CPU test emulation take the
+        kernel)."""
+        if defer and ops.LN_FUSE and x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad):
+            if pe is not None and (pe.dim() != 2 or pe.shape[1] != x.shape[-1] or frames <= 0 or rows_per_frame <= 0
+                                   or frame_offset < 0 or pe.shape[0] < frame_offset + frames):
+                return ops.layer_norm(x, self.weight, self.bias, self.eps, pe=pe, rows_per_frame=rows_per_frame,
+                                      frames=frames, frame_offset=frame_offset)        # raises the table-size error
+            return ops.DeferredLN(x, self.weight, self.bias, self.eps, pe, rows_per_frame, frames, frame_offset)
         return ops.layer_norm(x, self.weight, self.bias, self.eps, pe=pe, rows_per_frame=rows_per_frame,
                               frames=frames, frame_offset=frame_offset)
 

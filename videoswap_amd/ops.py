@@ -93,11 +93,123 @@ def gemm(desc):
     check(lib.vsx_gemm_f16(ctypes.byref(desc), stream), 'vsx_gemm_f16')
 
 
+# --------------------------------------------------------------------------------------------
+# LayerNorm folded into the Linear that consumes it (include/vsx.h: vsx_gemm_desc.rowscale / colvec)
+# --------------------------------------------------------------------------------------------
+LN_FUSE = os.environ.get('VSX_LN_FUSE', '1') != '0'     # 0: every LayerNorm runs as its own kernel (A/B runs)
+
+
+class DeferredLN:
+    """A LayerNorm that has not been applied: `x` is the RAW activation, and the Linear(s) consuming the normalised tensor
+    (attention.py:182,199,205 norm1/2/3 -> to_q / to_k / to_v / GEGLU; motion_module.py:213,219) apply it inside their
+    GEMM through  LN(x) W^T + b = rstd * (x (W o gamma)^T) - rstd * mean * sum_k (W o gamma) + (beta W^T + b)  (+ pe W^T for
+    the temporal positional encoding).  The normalised tensor is never written; the row statistics are computed once per
+    DeferredLN (`stats()`), whatever the number of consumers.  Quacks like the tensor the processors expect as far as they
+    use it (shape, reshape / view, dtype, device); `materialize()` is the ordinary kernel for anything else."""
+    is_cuda = True
+    requires_grad = False
+
+    def __init__(self, x, gamma, beta, eps, pe=None, rows_per_frame=0, frames=0, frame_offset=0, _shared=None):
+        self.x, self.gamma, self.beta, self.eps = x, gamma, beta, eps
+        self.pe, self.rows_per_frame, self.frames, self.frame_offset = pe, rows_per_frame, frames, frame_offset
+        self._shared = _shared if _shared is not None else {}          # stats / materialised tensor, shared by reshapes
+
+    shape = property(lambda self: self.x.shape)
+    dtype = property(lambda self: self.x.dtype)
+    device = property(lambda self: self.x.device)
+
+    def dim(self):
+        return self.x.dim()
+
+    def numel(self):
+        return self.x.numel()
+
+    def contiguous(self):
+        return self
+
+    def _like(self, x):
+        return DeferredLN(x, self.gamma, self.beta, self.eps, self.pe, self.rows_per_frame, self.frames, self.frame_offset,
+                          self._shared)
+
+    def reshape(self, *shape):
+        return self._like(self.x.reshape(*shape))
+
+    def view(self, *shape):
+        return self._like(self.x.view(*shape))
+
+    def stats(self):
+        """[M, 2] fp32 = (rstd, -rstd * mean) per row (vsx_row_stats), computed once"""
+        st = self._shared.get('stats')
+        if st is None:
+            C = self.x.shape[-1]
+            M = self.x.numel() // C
+            st = torch.empty(M, 2, dtype=torch.float32, device=self.x.device)
+            check(_lib.load().vsx_row_stats(_p(self.x), M, C, float(self.eps), _p(st), _stream()), 'vsx_row_stats')
+            self._shared['stats'] = st
+        return st
+
+    def materialize(self):
+        y = self._shared.get('y')
+        if y is None:
+            y = _raw['layer_norm'](self.x.reshape(-1, self.x.shape[-1]), self.gamma, self.beta, self.eps, pe=self.pe,
+                                   rows_per_frame=self.rows_per_frame, frames=self.frames, frame_offset=self.frame_offset)
+            self._shared['y'] = y
+        return y.view(self.x.shape)
+
+
+_fold_cache = {}      # (id(weight), id(gamma)) -> (stamp, weight ref, W o gamma, c1, c2); pe products hang off the entry
+
+
+def _ln_folded(weight, bias, ln):
+    """W' = W o gamma (fp16, the B operand), c1[n] = sum_k W'[n, k] (fp32), c2 = beta W^T + b (fp16, the epilogue bias);
+    rebuilt when any of the parameters changes (LoRA merge / load_state_dict bump the version)."""
+    import weakref
+    key = (id(weight), id(ln.gamma))
+    stamp = tuple((t.data_ptr(), t._version) for t in (weight, ln.gamma, ln.beta) + ((bias,) if bias is not None else ()))
+    hit = _fold_cache.get(key)
+    if hit is None or hit[0] != stamp or hit[1]() is not weight:
+        with torch.no_grad():
+            w32 = weight.detach().reshape(weight.shape[0], -1).float()
+            wf = (w32 * ln.gamma.detach().float()[None, :]).to(_F16).contiguous()
+            c1 = wf.float().sum(1).contiguous()
+            c2 = w32 @ ln.beta.detach().float()
+            if bias is not None:
+                c2 = c2 + bias.detach().float()
+            c2 = c2.to(_F16).contiguous()
+        if len(_fold_cache) > 4096:
+            _fold_cache.clear()
+        hit = (stamp, weakref.ref(weight), wf, c1, c2, {})
+        _fold_cache[key] = hit
+    return hit
+
+
+def _ln_pe_rows(hit, weight, ln, M):
+    """pe W^T as the GEMM's row-vector term: [M / rows_per_frame, N] (row m takes frame (m / rows_per_frame) % frames)"""
+    if ln.pe is None:
+        return None, 0
+    nblk = M // ln.rows_per_frame
+    key = (ln.pe.data_ptr(), ln.pe._version, ln.frame_offset, ln.frames, nblk)
+    rv = hit[5].get(key)
+    if rv is None:
+        with torch.no_grad():
+            pe = ln.pe[ln.frame_offset:ln.frame_offset + ln.frames].float()
+            rows = (pe @ weight.detach().reshape(weight.shape[0], -1).float().t()).to(_F16)        # [frames, N]
+            rv = rows.repeat(nblk // ln.frames, 1).contiguous()
+        if len(hit[5]) > 16:
+            hit[5].clear()
+        hit[5][key] = rv
+    return rv, ln.rows_per_frame
+
+
 def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
     """y = x @ weight.T (+bias) (+residual); geglu: weight is [2N,K], y = h * gelu(g).
 
-    x [..., K] -> [..., N].  Replaces nn.Linear / 1x1 conv / diffusers GEGLU.
+    x [..., K] -> [..., N].  Replaces nn.Linear / 1x1 conv / diffusers GEGLU.  `x` may be a DeferredLN: the LayerNorm is
+    then applied inside the GEMM.
     """
+    ln = x if isinstance(x, DeferredLN) else None
+    if ln is not None:
+        x = ln.x
     _chk(x, 'x'); _chk(weight, 'weight'); _chk(bias, 'bias'); _chk(residual, 'residual')
     K = x.shape[-1]
     M = x.numel() // K
@@ -116,6 +228,19 @@ def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
     d.B = weight.data_ptr(); d.ldb = K
     d.C = out.data_ptr(); d.ldc = N
     d.bias = bias.data_ptr() if bias is not None else None
+    keep = None
+    if ln is not None:
+        hit = _ln_folded(weight, bias, ln)
+        rv, rpv = _ln_pe_rows(hit, weight, ln, M)
+        if rv is not None and geglu:
+            raise _lib.VsxError('linear: a positional encoding cannot be folded into a GEGLU projection')
+        st = ln.stats()
+        keep = (hit, rv, st)
+        d.B = hit[2].data_ptr()
+        d.bias = hit[4].data_ptr()
+        d.rowscale, d.colvec = st.data_ptr(), hit[3].data_ptr()
+        if rv is not None:
+            d.rowvec, d.rows_per_vec = rv.data_ptr(), rpv
     if residual is not None:
         if residual.numel() != M * N:
             raise _lib.VsxError('linear: residual shape mismatch')
@@ -123,6 +248,7 @@ def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
     d.geglu = 1 if geglu else 0
     d.alpha = 1.0
     gemm(d)
+    del keep
     return out
 
 
@@ -132,6 +258,9 @@ def linear_vt(x, weight, bias, rows_per_img, ldvt=None):
     Feeds vsx_attention_f16 / attention_pv (V is consumed key-contiguous).  Columns >= rows of VT are left
     untouched (the consumers mask them).
     """
+    ln = x if isinstance(x, DeferredLN) else None
+    if ln is not None:
+        x = ln.x
     _chk(x, 'x'); _chk(weight, 'weight'); _chk(bias, 'bias')
     K = x.shape[-1]
     M = x.numel() // K
@@ -150,8 +279,19 @@ def linear_vt(x, weight, bias, rows_per_img, ldvt=None):
     d.C = vt.data_ptr(); d.ldc = ldvt
     d.c_mode = 1; d.c_rows_per_img = rows_per_img; d.c_img_stride = N * ldvt
     d.bias = bias.data_ptr() if bias is not None else None
+    keep = None
+    if ln is not None:
+        if ln.pe is not None:
+            raise _lib.VsxError('linear_vt: a positional encoding cannot be folded into the transposed V projection')
+        hit = _ln_folded(weight, bias, ln)
+        st = ln.stats()
+        keep = (hit, st)
+        d.B = hit[2].data_ptr()
+        d.bias = hit[4].data_ptr()
+        d.rowscale, d.colvec = st.data_ptr(), hit[3].data_ptr()
     d.alpha = 1.0
     gemm(d)
+    del keep
     return vt
 
 
@@ -390,6 +530,8 @@ def group_norm(x, gamma, beta, groups, eps, nimg, silu=False, x2=None, partial_h
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0, frame_offset=0):
+    if isinstance(x, DeferredLN):
+        raise _lib.VsxError('layer_norm of a deferred LayerNorm: materialize() it first')
     _chk(x, 'x'); _chk(gamma, 'gamma'); _chk(beta, 'beta'); _chk(pe, 'pe')
     C = x.shape[-1]
     if pe is not None:

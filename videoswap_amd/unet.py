@@ -141,9 +141,10 @@ class BasicTransformerBlock(nn.Module):
         return ops.axpy(attn(normed, encoder_hidden_states=text), x)
 
     def forward(self, x, encoder_hidden_states=None, timestep=None, attention_mask=None, video_length=None):
-        x = self._attend(self.attn1, self.norm1(x), x, None, video_length)
-        x = self._attend(self.attn2, self.norm2(x), x, encoder_hidden_states, video_length)
-        return self.ff(self.norm3(x), residual=x)
+        # the LayerNorms are folded into the projections that consume them when the processor is one of this package's
+        x = self._attend(self.attn1, self.norm1(x, defer=_native(self.attn1)), x, None, video_length)
+        x = self._attend(self.attn2, self.norm2(x, defer=_native(self.attn2)), x, encoder_hidden_states, video_length)
+        return self.ff(self.norm3(x, defer=True), residual=x)
 
 
 @dataclass
@@ -210,12 +211,12 @@ class TemporalTransformerBlock(nn.Module):
             if _native(attn):
                 pe = proc.pe_table() if hasattr(proc, 'pe_table') else None
                 normed = norm(x, pe=pe, rows_per_frame=hw, frames=video_length,
-                              frame_offset=getattr(proc, 'frame_offset', 0))
+                              frame_offset=getattr(proc, 'frame_offset', 0), defer=True)
                 x = attn(normed, encoder_hidden_states=None, video_length=video_length, residual=x,
                          pe_applied=pe is not None)
             else:
                 x = ops.axpy(attn(norm(x), encoder_hidden_states=None, video_length=video_length), x)
-        return self.ff(self.ff_norm(x), residual=x)
+        return self.ff(self.ff_norm(x, defer=True), residual=x)
 
 
 class TemporalTransformer3DModel(nn.Module):
