@@ -55,7 +55,9 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
             ('4', '0,1'),                        # GEGLU epilogue
             ('6', '0,2'),                        # 128-row tiles, GEGLU, ragged M
             ('7', '0,8'),                        # 36 tiles, tiles_n = 12: the 2-D walk against the linear one
-            ('8', '0,2')]                        # 3x3 convolution, two sources
+            ('8', '0,1'),                        # LayerNorm folded into the GEMM (rowscale / colvec), ragged M, residual
+            ('9', '0'),                          # ... and through the GEGLU epilogue
+            ('10', '0,2')]                       # 3x3 convolution, two sources
     for case, scheds in runs:
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900)
         print(r.stdout)

@@ -43,7 +43,7 @@ static std::vector<half_t> randh(size_t n, float scale = 1.0f) {
 }
 static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
 
-struct Case { const char* name; long M, N, K; bool res, geglu; int bm; };
+struct Case { const char* name; long M, N, K; bool res, geglu; int bm; bool ln = false; };
 
 static int n_bad = 0;
 static std::vector<long> g_scheds = {0, 1, 2, 8, 9};      // piece schedules 0-2; + 8: linear tile walk instead of the 2-D one
@@ -67,6 +67,14 @@ static void run_case(const Case& c) {
         for (long n = 0; n < brows; ++n) for (long k = 0; k < c.K; ++k) B[n * c.K + k] = (half_t)(float)(k);
         for (auto& b : bias) b = (half_t)0.f;
     }
+    // LayerNorm folded into the GEMM (rowscale / colvec): out = rs[m] * acc + rt[m] * c1[n] + bias ...
+    std::vector<float> rowscale, colvec;
+    if (c.ln) {
+        rowscale.resize(2 * c.M);
+        colvec.resize(brows);
+        for (long m = 0; m < c.M; ++m) { rowscale[2 * m] = 0.5f + 0.01f * (float)(m % 37); rowscale[2 * m + 1] = -0.3f + 0.02f * (float)(m % 11); }
+        for (long n = 0; n < brows; ++n) { double s = 0; for (long k = 0; k < c.K; ++k) s += (double)B[n * c.K + k]; colvec[n] = (float)s; }
+    }
     // reference
     std::vector<double> want(c.M * c.N);
     for (long m = 0; m < c.M; ++m)
@@ -74,6 +82,7 @@ static void run_case(const Case& c) {
             auto dot = [&](long row) {
                 double s = 0;
                 for (long k = 0; k < c.K; ++k) s += (double)A[m * c.K + k] * (double)B[row * c.K + k];
+                if (c.ln) s = (double)rowscale[2 * m] * s + (double)rowscale[2 * m + 1] * (double)colvec[row];
                 return s + (double)bias[row];
             };
             double v = c.geglu ? dot(n) * gelu(dot(c.N + n)) : dot(n);
@@ -86,6 +95,8 @@ static void run_case(const Case& c) {
         GemmParams p{};
         p.A = A.data(); p.B = B.data(); p.C = C.data(); p.bias = bias.data();
         p.residual = c.res ? R.data() : nullptr;
+        p.rowscale = c.ln ? rowscale.data() : nullptr;
+        p.colvec = c.ln ? colvec.data() : nullptr;
         p.M = c.M; p.N = c.N; p.K = c.K;
         p.lda = c.K; p.ldb = c.K; p.ldc = c.N; p.ldr = c.N;
         p.batch1 = 1; p.rows_per_vec = 1; p.geglu = c.geglu; p.alpha = 1.0f;
@@ -203,6 +214,8 @@ int main(int argc, char** argv) {
         {"plain 384x320x64 (+res) 128-row", 384, 320, 64, true, false, 128},  // one slab per tile
         {"geglu 300x320x192 128-row", 300, 320, 192, false, true, 128},
         {"wide 768x3840x64 (2-D walk, 36 tiles)", 768, 3840, 64, false, false, 256},     // tiles_n = 12: blocks of 8 x 4
+        {"rowscale 600x320x128 (+res)", 600, 320, 128, true, false, 256, true},         // LayerNorm identity, ragged M
+        {"rowscale geglu 300x160x64 128-row", 300, 160, 64, false, true, 128, true},
     };
     // usage: check_gemm_pp [case index | -1 = all] [comma-separated schedules]
     cpuhip_num_cus = 24;                  // three workgroups per emulated XCD: blockIdx.x >> 3 takes the values 0, 1, 2

@@ -66,6 +66,15 @@ static inline float __shfl_xor(float v, int mask, int width = 64) {
     cpuhip::ctx.wave_bar->arrive_and_wait();
     return r;
 }
+static inline float __shfl(float v, int src, int width = 64) {
+    (void)width;
+    const int lane = (int)(cpuhip::ctx.tid.x & 63);
+    cpuhip::ctx.wave_slots[lane] = v;
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    const float r = cpuhip::ctx.wave_slots[src & 63];
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    return r;
+}
 #define __expf(x) expf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }

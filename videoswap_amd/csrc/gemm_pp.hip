@@ -91,7 +91,8 @@ __device__ __forceinline__ void tile_coords(const int tile, const int tiles_n, c
 
 template <int CW>                   // chunk width in output columns: 64, 32 or 16
 __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, const int lane, const int mblk,
-                                              const int ncol, const bool add_bias) {
+                                              const int ncol, const bool add_bias, const float st_rs = 1.f,
+                                              const float st_rt = 0.f) {
     constexpr int STRIDE = CW + 4;                  // floats per staged row
     constexpr int LPR = CW / 8;                     // lanes per row (8 columns each)
     constexpr int RPP = 64 / LPR;                   // rows per pass
@@ -106,7 +107,10 @@ __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, con
 #pragma unroll
         for (int e = 0; e < 8; ++e) bv[e] = (float)b[e];
     }
-    const float* rsp = add_bias ? p->rowscale : nullptr;         // LayerNorm identity (plain path: applied here)
+    // LayerNorm identity (plain path: applied here).  st_rs / st_rt: lane l holds (rstd, -rstd * mean) of row mblk + l % 32,
+    // loaded ONCE per 32-row block by the caller; a pass fetches its row's pair with two cross-lane reads (a global load
+    // per pass put a dependent L2 round trip in front of every one of the 24 passes of a tile: + 8 % on the K = 320 GEMMs)
+    const float* rsp = add_bias ? p->rowscale : nullptr;
     float cv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cv[e] = 0.f;
@@ -123,12 +127,13 @@ __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, con
     for (int pass = 0; pass < 32 / RPP; ++pass) {
         const int row = pass * RPP + r0;
         const int m = mblk + row;
+        const float rs = rsp ? __shfl(st_rs, row, 64) : 1.f;      // (all lanes take part, also those past M)
+        const float rt = rsp ? __shfl(st_rt, row, 64) : 0.f;
         if (m >= Mi) continue;
         const f4v a = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8);
         const f4v b = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8 + 4);
         float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         if (rsp) {
-            const float rs = rsp[2 * (unsigned)m], rt = rsp[2 * (unsigned)m + 1];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(rs, o[e], rt * cv[e]);
         }
@@ -220,6 +225,12 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
             continue;
         }
         // plain: chunks j = {0, 1}, {2, 3} (64 columns: one full 128-byte line per row), {4} (32 columns)
+        float st_rs = 1.f, st_rt = 0.f;
+        if (p->rowscale) {
+            const unsigned mr = (unsigned)min(mblk + l31, (int)p->M - 1);
+            st_rs = p->rowscale[2 * mr];
+            st_rt = p->rowscale[2 * mr + 1];
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int j0 = c * 2, nj = c < 2 ? 2 : 1;
@@ -235,8 +246,8 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (c < 2) epilogue_rows<64>(p, stg, lane, mblk, ncol0 + j0 * 32, true);
-            else epilogue_rows<32>(p, stg, lane, mblk, ncol0 + j0 * 32, true);
+            if (c < 2) epilogue_rows<64>(p, stg, lane, mblk, ncol0 + j0 * 32, true, st_rs, st_rt);
+            else epilogue_rows<32>(p, stg, lane, mblk, ncol0 + j0 * 32, true, st_rs, st_rt);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
