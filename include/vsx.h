@@ -46,7 +46,7 @@ const char* vsx_last_error(void);
  * sources it sits next to and refuses a stale binary. */
 const char* vsx_source_digest(void);
 /* Tuning / test switch (process-wide, not thread-safe against concurrent launches): "gemm_pp" = 0 never / 1 default /
- * 2 always-when-eligible use of the persistent ping-pong GEMM kernel; "pp_sched" = its DMA schedule variant.  Results
+ * 2 always-when-eligible use of the persistent ping-pong GEMM kernel; "pp_sched" = its option bits (8: linear tile walk).  Results
  * are identical for every setting (same arithmetic, same summation order per output element). */
 int vsx_set_option(const char* name, int64_t value);
 

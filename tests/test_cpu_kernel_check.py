@@ -38,9 +38,9 @@ def test_backward_kernels_run_from_source_on_the_cpu(tmp_path):
 def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
     """videoswap_amd/csrc/gemm_pp.hip (the shipped persistent kernel) under tools/cpu_check/hip_gemm.h (MFMA as a wave
     collective with the hardware's fragment layout, LDS-DMA as a synchronous 16-byte-per-lane copy with the descriptor's
-    range check, wave lockstep at the scheduling barriers): every piece schedule of `pp_sched`, under the default 2-D
-    tile walk and under the linear one (+ 8), must reproduce a double-precision GEMM / convolution, bit for bit like
-    variant 0, without a single read past a tensor.  (What this cannot see is the
+    range check, wave lockstep at the scheduling barriers): every epilogue kind the kernel is compiled for, under the
+    default 2-D tile walk and under the linear one (pp_sched 8), must reproduce a double-precision GEMM / convolution, the
+    two walks bit for bit alike, without a single read past a tensor.  (What this cannot see is the
     asynchronous ordering of the real DMA; the late-landing run below covers the other extreme of it.)  A subset of
     `make -C tools/cpu_check run`: one case per epilogue / loader kind."""
     cxx = CXX if os.path.isfile(CXX) else shutil.which('clang++')
@@ -51,20 +51,23 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
            os.path.join(src, 'check_gemm_pp.cpp')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    runs = [('0', '0,1,2,8'),                    # one 256x320 tile, one slab: every variant
-            ('4', '0,1'),                        # GEGLU epilogue
-            ('6', '0,2'),                        # 128-row tiles, GEGLU, ragged M
+    runs = [('0', '0,8'),                        # one 256x320 tile, one slab
+            ('4', '0'),                          # GEGLU epilogue
+            ('6', '0'),                          # 128-row tiles, GEGLU, ragged M
             ('7', '0,8'),                        # 36 tiles, tiles_n = 12: the 2-D walk against the linear one
-            ('8', '0,1'),                        # LayerNorm folded into the GEMM (rowscale / colvec), ragged M, residual
-            ('9', '0'),                          # ... and through the GEGLU epilogue
-            ('10', '0,2')]                       # 3x3 convolution, two sources
+            ('8', '0'),                          # LayerNorm folded into the GEMM (rowscale / colvec), ragged M, residual ring
+            ('9', '0'),                          # ... through the GEGLU epilogue
+            ('10', '0'),                         # ... alone
+            ('12', '0'),                         # 3x3 convolution, two sources, row-vector ring
+            ('13', '0'),                         # stride 2, 128-row tiles
+            ('16', '0')]                         # 48 rows per vector: 32-row blocks that meet two row vectors
     for case, scheds in runs:
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900)
         print(r.stdout)
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     # ordering hazards: the multi-tile, multi-slab case again with every DMA piece landing as LATE as the kernel's own
     # waits allow (the default run above lands them at issue, the other extreme); see tools/cpu_check/hip_gemm.h
-    r = subprocess.run([exe, '1', '0,2,8'], capture_output=True, text=True, timeout=900,
+    r = subprocess.run([exe, '1', '0,8'], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, CPUHIP_DMA='late'))
     print(r.stdout)
     assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

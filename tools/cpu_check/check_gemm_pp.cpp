@@ -1,6 +1,6 @@
-// Runs the persistent ping-pong GEMM (videoswap_amd/csrc/gemm_pp.hip) on the CPU from its real source — every piece
-// schedule of `pp_sched`, the 2-D and the linear tile walk, both tile heights, plain / residual / GEGLU epilogues — and
-// compares with a double-precision GEMM; the variants must also agree bit for bit with variant 0, and the 2-D tile walk
+// Runs the persistent ping-pong GEMM (videoswap_amd/csrc/gemm_pp.hip) on the CPU from its real source — the 2-D and the
+// linear tile walk, both tile heights, every epilogue kind (plain / addend ring / folded LayerNorm / GEGLU) — and
+// compares with a double-precision GEMM; the walks must also agree bit for bit, and the 2-D tile walk
 // must be a permutation of the tiles.  See hip_gemm.h for what the emulation covers (addressing, LDS layout, MFMA fragment layout, epilogue) and
 // what it cannot (the asynchronous ordering of the LDS-DMA).
 #define CPUHIP_DYNAMIC_LDS_ONLY
@@ -46,7 +46,7 @@ static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
 struct Case { const char* name; long M, N, K; bool res, geglu; int bm; bool ln = false; };
 
 static int n_bad = 0;
-static std::vector<long> g_scheds = {0, 1, 2, 8, 9};      // piece schedules 0-2; + 8: linear tile walk instead of the 2-D one
+static std::vector<long> g_scheds = {0, 8};      // pp_sched bits: 8 = linear tile walk instead of the 2-D one
 
 static std::vector<half_t> pack_b(const std::vector<half_t>& w, long rows, long K) {      // [N/8][K/64][8][64]
     std::vector<half_t> out(w.size());
@@ -216,6 +216,8 @@ int main(int argc, char** argv) {
         {"wide 768x3840x64 (2-D walk, 36 tiles)", 768, 3840, 64, false, false, 256},     // tiles_n = 12: blocks of 8 x 4
         {"rowscale 600x320x128 (+res)", 600, 320, 128, true, false, 256, true},         // LayerNorm identity, ragged M
         {"rowscale geglu 300x160x64 128-row", 300, 160, 64, false, true, 128, true},
+        {"rowscale 700x320x64", 700, 320, 64, false, false, 256, true},                  // LayerNorm identity alone
+        {"rowscale 200x640x128 (+res) 128-row", 200, 640, 128, true, false, 128, true},
     };
     // usage: check_gemm_pp [case index | -1 = all] [comma-separated schedules]
     cpuhip_num_cus = 24;                  // three workgroups per emulated XCD: blockIdx.x >> 3 takes the values 0, 1, 2
@@ -228,9 +230,11 @@ int main(int argc, char** argv) {
     for (int i = 0; i < ncases; ++i)
         if (only < 0 || only == i) run_case(cases[i]);
     if (only < 0 || only == ncases) run_conv("conv3x3 2x8x8 64+64->320", 2, 8, 8, 64, 64, 320, 1, 0, 256);
-    if (only < 0 || only == ncases + 1) run_conv("conv3x3 3x12x8 128->320 /s2 128-row", 3, 12, 8, 128, 0, 320, 2, 0, 128);
+    if (only < 0 || only == ncases + 1) run_conv("conv3x3 3x16x8 128->320 /s2 128-row", 3, 16, 8, 128, 0, 320, 2, 0, 128);    // 32 rows per vector
     if (only < 0 || only == ncases + 2) run_conv("conv3x3 2x8x8 64->320 nearest-2x", 2, 8, 8, 64, 0, 320, 1, 1, 128);
     if (only < 0 || only == ncases + 3) run_conv("conv3x3 1x16x16 128+64->320", 1, 16, 16, 128, 64, 320, 1, 0, 256);
+    if (only < 0 || only == ncases + 4)      // 48 rows per vector: 32-row blocks that meet two row vectors
+        run_conv("conv3x3 3x6x8 64->320", 3, 6, 8, 64, 0, 320, 1, 0, 256);
     if (only < 0) {          // the 2-D tile walk visits every tile exactly once (any tile count, ragged last super-row)
         int bad = 0;
         for (int tn : {1, 2, 6, 8, 12, 16, 24, 32, 40, 44})

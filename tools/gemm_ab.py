@@ -3,7 +3,7 @@ persistent ping-pong kernel with 256-row tiles (gemm_pp = 2), with 128-row tiles
 (gemm_pp = 1, what the product runs).
 
     python tools/gemm_ab.py [--batch 2] [--rounds 5] > gpurun_out/gemm_ab.txt
-    python tools/gemm_ab.py --scheds 0,4,8,12,16,32    # option bits of pp_sched (gemm_common.h PP_*):
+    python tools/gemm_ab.py --scheds 0,8                # option bits of pp_sched (gemm_common.h PP_*):
                                                                           # tile kernels vs 256-row persistent tiles per schedule
 
 Variants are interleaved round by round inside ONE process (a cross-process comparison has >3 % noise); the table shows
@@ -99,12 +99,12 @@ def main():
     ap.add_argument('--batch', type=int, default=2)
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--reps', type=int, default=4)
-    ap.add_argument('--scheds', default='', help='comma-separated pp_sched values: compare piece schedules instead of tile sizes')
+    ap.add_argument('--scheds', default='', help='comma-separated pp_sched values: compare option bits instead of tile sizes')
     ap.add_argument('--bm', type=int, default=256, choices=(128, 256), help='row tile of the --scheds comparison')
     args = ap.parse_args()
     variants = [('tile', 0, 0), ('pp256', 2, 0), ('pp128', 3, 0), ('auto', 1, 0)]
     if args.scheds:
-        def label(n):           # pp_sched bits: 0-1 piece cut, 4 conv slab order, 8 2-D tile walk, 16 no prio, 32 prio on LOAD
+        def label(n):           # pp_sched bits: 8 = linear tile walk
             n = int(n)
             return f'pp{args.bm}/s{n}'
         variants = [('tile', 0, 0)] + [(label(n), 2 if args.bm == 256 else 3, int(n)) for n in args.scheds.split(',')]

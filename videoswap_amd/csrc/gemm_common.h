@@ -31,15 +31,16 @@ struct GemmParams {
     float* ws;
     float alpha;
     int tiles_total;                       // persistent kernel: number of output tiles
-    int pp_flags;                          // persistent kernel: PP_* option bits (tile walk, conv slab order, priority)
+    int pp_flags;                          // persistent kernel: PP_* option bits (tile walk)
 };
 
-// pp_flags: option bits of "pp_sched" / VSX_PP_SCHED above the piece-schedule variant (bits 0-1).  Round 3 measured five
-// candidates on the GPU (profiles/r03_gemm_option_ab*_b2.txt) and kept one: the 2-D tile walk inside an XCD is the default
-// (same speed, 2.5x less HBM traffic on the wide-N GEMMs); 8 restores the linear walk for A/B runs.  Dropped: conv slab
-// order "taps of a channel slab back to back" (8-13 % slower: the per-slab address update runs on the VALU, which is
-// blocked while the partner wave streams MFMAs), no s_setprio / s_setprio on the LOAD phase (+-1 %), K-start stagger per
-// workgroup (+5-9 % in tools/ubench/gemm_loop.hip, -6 ... +10 % in the kernel: no net gain).
+// pp_flags: option bits of "pp_sched" / VSX_PP_SCHED.  Round 3 measured five candidates on the GPU
+// (profiles/r03_gemm_option_ab*_b2.txt, r03_gemm_sched_ab_b2.txt) and kept one: the 2-D tile walk inside an XCD is the
+// default (same speed, 2.5x less HBM traffic on the wide-N GEMMs); 8 restores the linear walk for A/B runs.  Dropped:
+// other cut points of the DMA piece schedule (+-1 %), conv slab order "taps of a channel slab back to back" (8-13 %
+// slower: the per-slab address update runs on the VALU, which is blocked while the partner wave streams MFMAs), no
+// s_setprio / s_setprio on the LOAD phase (+-1 %), K-start stagger per workgroup (+5-9 % in tools/ubench/gemm_loop.hip,
+// -6 ... +10 % in the kernel: no net gain).
 constexpr int PP_TILES_LINEAR = 8;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -54,7 +55,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // Tuning / test switches (vsx_set_option; initial values from the environment): "gemm_pp" (VSX_GEMM_PP: 0 = never use
 // the persistent kernel, 1 = where it is expected to win, 2 = wherever the shape is eligible), "pp_sched"
-// (VSX_PP_SCHED: DMA piece schedule variant).
+// (VSX_PP_SCHED: PP_* bits).
 long gemm_option(const char* name);
 
 // gemm_pp.hip: persistent ping-pong kernel (256x320 / 128x320 tiles).  `bm` selects the row tile.

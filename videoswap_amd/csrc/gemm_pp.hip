@@ -43,6 +43,7 @@ namespace vsxg {
 namespace {
 
 typedef const __attribute__((address_space(4))) GemmParams* kparams_t;
+typedef float f2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ kparams_t kernarg_params() {
     kparams_t kp = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();   // GemmParams is the first kernel argument
@@ -89,97 +90,182 @@ __device__ __forceinline__ void tile_coords(const int tile, const int tiles_n, c
     tile_n = cb * CB + (within - r * CB);
 }
 
-template <int CW>                   // chunk width in output columns: 64, 32 or 16
+// ---- What the epilogue may NOT do: wait for a global load it has just issued.  vmcnt counts loads and stores in issue
+// order, so a wait for the newest load is vmcnt(0): it also waits for every store before it to be acknowledged.  The first
+// staged epilogue loaded bias, row vector and residual where it used them, pass by pass: 24 x "load, wait for it and
+// for the last store, store" per tile with 16 bytes per lane in flight (measured: the +res epilogue of a K = 320 tile took
+// twice as long as its five K slabs, ~2 TB/s of residual reads chip-wide).  Now:
+//  * the per-COLUMN constants of the wave's 160 columns (bias, and c1 of a folded LayerNorm) are loaded once per tile,
+//    together with the per-row LayerNorm pairs and ahead of everything else, and parked as fp32 in the slack of the
+//    wave's staging area; the chunks read them from LDS;
+//  * the ADDEND (residual, or the row vector when there is no residual) is fetched through a ring of PD (4; 3 in the
+//    convolution kernel, 2 beside the LayerNorm registers: what fits without spilling) 16-byte registers per lane.  A
+//    wave's epilogue is a flat sequence of 10 * TM row passes (per 32-row block: 4 + 4 passes of 8 rows x 64 columns,
+//    then 2 passes of 16 rows x 32 columns); pass f consumes ring entry f % PD and refills it with the addend of pass
+//    f + PD, so the wait before a pass is vmcnt(PD - 1 + stores since) and PD KiB per wave stay in flight.
+constexpr int EP_CONST = 8704 / 4;  // float offset of the column constants in a wave's staging area: [160] bias, [160] c1
+static_assert(8704 + 2 * 160 * 4 <= EP_BYTES, "column constants fit behind the staged chunk");
+
+struct PreSrc {
+    const half_t* src;      // residual or row vector
+    bool is_rowvec;
+    unsigned pitch;         // ldr or N
+    unsigned v0[2], bnd[2]; // row vector: index of the vector of a 32-row block's first row, first row of the next vector
+    int mrow0, ncol0, Mlast;
+};
+
+template <int PD>
+__device__ __forceinline__ void pre_fetch(const PreSrc& ps, const int lane, const int f, h8* pre) {
+    const int i = f / 10, r = f % 10;
+    const int c = r < 4 ? 0 : (r < 8 ? 1 : 2);
+    const int pass = r - 4 * c;
+    const int lpr = c < 2 ? 8 : 4, rpp = c < 2 ? 8 : 16;
+    const int n = ps.ncol0 + c * 64 + (lane % lpr) * 8;
+    const unsigned m = (unsigned)min(ps.mrow0 + i * 32 + pass * rpp + lane / lpr, ps.Mlast);   // rows past M: the last row
+    // row vector: rows_per_vec >= 32, so the block meets at most two vectors (no per-lane division)
+    const unsigned row = ps.is_rowvec ? ps.v0[i] + (m >= ps.bnd[i] ? 1u : 0u) : m;
+    pre[f % PD] = *reinterpret_cast<const h8*>(ps.src + (row * ps.pitch + (unsigned)n));
+}
+
+// One staged chunk (32 rows x CW columns, fp32, row-major in `stg`) -> C.  cst: the wave's column constants + the float
+// offset of this chunk's first column in them (nullptr: no bias / LayerNorm, the GEGLU path has applied them).  PD > 0:
+// a prefetched addend exists (fbase: flat index of the chunk's first pass, nf: passes of the whole epilogue).  LN:
+// LayerNorm folded into the GEMM — lane l holds (rstd, -rstd * mean) of row mblk + l % 32 in st_rs / st_rt; a pass
+// fetches its row's pair with two cross-lane reads.  Same fp32 operation order as gemm.hip's epilogue (scale, LayerNorm
+// identity, bias, row vector | residual).
+template <int CW, int PD, bool LN>           // CW: chunk width in output columns: 64, 32 or 16; PD: ring depth (0: no addend)
 __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, const int lane, const int mblk,
-                                              const int ncol, const bool add_bias, const float st_rs = 1.f,
+                                              const int ncol, const float* cst, const PreSrc& ps, h8* pre,
+                                              const int fbase, const int nf, const float st_rs = 1.f,
                                               const float st_rt = 0.f) {
+    constexpr bool ADD = PD > 0;
     constexpr int STRIDE = CW + 4;                  // floats per staged row
     constexpr int LPR = CW / 8;                     // lanes per row (8 columns each)
     constexpr int RPP = 64 / LPR;                   // rows per pass
-    const int Mi = (int)p->M, Ni = (int)p->N;
+    const int Mi = (int)p->M;
     const int col8 = (lane % LPR) * 8, r0 = lane / LPR;
     const int n = ncol + col8;
-    float bv[8];
+    float bv[8], cv[LN ? 8 : 1];
+    if (cst) {
+        const f4v b0 = *reinterpret_cast<const f4v*>(cst + col8), b1 = *reinterpret_cast<const f4v*>(cst + col8 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-    if (add_bias && p->bias) {
-        const h8 b = *reinterpret_cast<const h8*>(p->bias + n);
+        for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[e + 4] = b1[e]; }
+        if constexpr (LN) {
+            const f4v c0 = *reinterpret_cast<const f4v*>(cst + 160 + col8), c1 = *reinterpret_cast<const f4v*>(cst + 164 + col8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (float)b[e];
+            for (int e = 0; e < 4; ++e) { cv[e] = c0[e]; cv[e + 4] = c1[e]; }
+        }
     }
-    // LayerNorm identity (plain path: applied here).  st_rs / st_rt: lane l holds (rstd, -rstd * mean) of row mblk + l % 32,
-    // loaded ONCE per 32-row block by the caller; a pass fetches its row's pair with two cross-lane reads (a global load
-    // per pass put a dependent L2 round trip in front of every one of the 24 passes of a tile: + 8 % on the K = 320 GEMMs)
-    const float* rsp = add_bias ? p->rowscale : nullptr;
-    float cv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cv[e] = 0.f;
-    if (rsp) {
-        const f4v c0 = *reinterpret_cast<const f4v*>(p->colvec + n), c1 = *reinterpret_cast<const f4v*>(p->colvec + n + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { cv[e] = c0[e]; cv[e + 4] = c1[e]; }
-    }
-    const half_t* rvp = p->rowvec;
-    const half_t* resp = p->residual;
     half_t* cp = p->C;
-    const unsigned ldc = (unsigned)p->ldc, ldr = (unsigned)p->ldr, rpv = (unsigned)p->rows_per_vec;
+    const unsigned ldc = (unsigned)p->ldc;
 #pragma unroll
     for (int pass = 0; pass < 32 / RPP; ++pass) {
         const int row = pass * RPP + r0;
         const int m = mblk + row;
-        const float rs = rsp ? __shfl(st_rs, row, 64) : 1.f;      // (all lanes take part, also those past M)
-        const float rt = rsp ? __shfl(st_rt, row, 64) : 0.f;
-        if (m >= Mi) continue;
         const f4v a = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8);
         const f4v b = *reinterpret_cast<const f4v*>(stg + row * STRIDE + col8 + 4);
         float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        if (rsp) {
+        if constexpr (LN) {
+            const float rs = __shfl(st_rs, row, 64), rt = __shfl(st_rt, row, 64);   // (all lanes take part, also those past M)
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(rs, o[e], rt * cv[e]);
         }
-        if (add_bias && p->bias) {
+        if (cst) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] += bv[e];
         }
-        if (rvp) {
-            const h8 v = *reinterpret_cast<const h8*>(rvp + ((unsigned)m / rpv) * (unsigned)Ni + n);
+        if constexpr (ADD) {
+            const h8 add = pre[(fbase + pass) % PD];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += (float)v[e];
-        }
-        if (resp) {
-            const h8 v = *reinterpret_cast<const h8*>(resp + (unsigned)m * ldr + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += (float)v[e];
+            for (int e = 0; e < 8; ++e) o[e] += (float)add[e];
+            if (fbase + pass + PD < nf) pre_fetch<PD>(ps, lane, fbase + pass + PD, pre);
         }
         h8 pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pk[e] = (half_t)o[e];
-        *reinterpret_cast<h8*>(cp + (unsigned)m * ldc + n) = pk;
+        if (m < Mi) *reinterpret_cast<h8*>(cp + ((unsigned)m * ldc + (unsigned)n)) = pk;
     }
 }
 
-template <int TM>
+// EPI: what the epilogue does besides scale and bias — compiled per combination, so that a launch carries only the
+// registers and branches of its own epilogue (the K loop runs at 253 of 256 registers).
+constexpr int EPI_ADD = 1;          // + residual, or + row vector (one of the two: prefetched ring)
+constexpr int EPI_LN = 2;           // LayerNorm folded into the GEMM (rowscale / colvec)
+constexpr int EPI_GEGLU = 4;        // h * gelu(g)
+
+template <int TM, int EPI, int PD>
 __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, const int mrow0, const int ncol0,
                                             const int gcol0, const int lane) {
+    constexpr bool ADD = (EPI & EPI_ADD) != 0, LN = (EPI & EPI_LN) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
     kparams_t p = kernarg_params();
     const int l31 = lane & 31, hi = lane >> 5;
     const float alpha = p->alpha;
+    // ---- loads of the tile's constants, issued before anything else.  Column constants: lane l < 40 owns 4 of the wave's
+    // 160 columns (plain: ncol0 + 4l; GEGLU: h columns gcol0 + 4l for l < 20, the matching g columns N + gcol0 + 4(l - 20))
+    const half_t* bias = p->bias;
+    const int Ni = (int)p->N;
+    const int ccol = GEGLU ? (lane < 20 ? gcol0 + 4 * lane : Ni + gcol0 + 4 * (lane - 20)) : ncol0 + 4 * lane;
+    h4 cb = {};
+    f4v cc = {};
+    if (lane < 40) {
+        if (bias) cb = *reinterpret_cast<const h4*>(bias + ccol);
+        if constexpr (LN) cc = *reinterpret_cast<const f4v*>(p->colvec + ccol);
+    }
+    // LayerNorm folded into the GEMM: the (rstd, -rstd * mean) pairs of this wave's rows, all blocks at once
+    float st_rs[TM], st_rt[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mblk = mrow0 + i * 32;
-        if (p->geglu) {
-            // tile j: registers 0-7 are h of 16 output columns, registers 8-15 the matching g.  The activation (which
-            // needs the bias first) is computed in the fragment layout; chunks: j = 0..3 (64 columns), j = 4 (16)
-            const half_t* bias = p->bias;
-            const int Ni = (int)p->N;
-            const float* rsp = p->rowscale;
-            const float* cvp = p->colvec;
-            float rs = 1.f, rt = 0.f;
-            if (rsp) {
-                const unsigned mr = (unsigned)min(mblk + l31, (int)p->M - 1);
-                rs = rsp[2 * mr];
-                rt = rsp[2 * mr + 1];
+    for (int i = 0; i < TM; ++i) { st_rs[i] = 1.f; st_rt[i] = 0.f; }
+    if constexpr (LN) {
+        const float* rsp = p->rowscale;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned mr = (unsigned)min(mrow0 + i * 32 + l31, (int)p->M - 1);
+            const f2v v = *reinterpret_cast<const f2v*>(rsp + 2 * mr);
+            st_rs[i] = v[0];
+            st_rt[i] = v[1];
+        }
+    }
+    PreSrc ps = {};
+    constexpr int NF = 10 * TM;
+    h8 pre[ADD ? PD : 1];
+    if constexpr (ADD) {
+        const half_t* resp = p->residual;
+        ps.src = resp ? resp : p->rowvec;
+        ps.is_rowvec = resp == nullptr;
+        ps.pitch = ps.is_rowvec ? (unsigned)p->N : (unsigned)p->ldr;
+        ps.mrow0 = mrow0;
+        ps.ncol0 = ncol0;
+        ps.Mlast = (int)p->M - 1;
+        if (ps.is_rowvec) {
+            const unsigned rpv = (unsigned)p->rows_per_vec;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ps.v0[i] = (unsigned)min(mrow0 + i * 32, ps.Mlast) / rpv;       // wave-uniform
+                ps.bnd[i] = (ps.v0[i] + 1u) * rpv;
             }
+        }
+#pragma unroll
+        for (int f = 0; f < PD; ++f) pre_fetch<PD>(ps, lane, f, pre);
+    }
+    float* cst = stg + EP_CONST;
+    auto park_constants = [&]() {               // after the first chunk's ds_writes: the loads above have had that long
+        if (lane < 40) {
+            f4v bf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bf[e] = (float)cb[e];
+            *reinterpret_cast<f4v*>(cst + 4 * lane) = bf;
+            if constexpr (LN) *reinterpret_cast<f4v*>(cst + 160 + 4 * lane) = cc;
+        }
+    };
+    if constexpr (GEGLU) {
+        // tile j: registers 0-7 are h of 16 output columns, registers 8-15 the matching g.  The activation (which
+        // needs the bias first) is computed in the fragment layout; chunks: j = 0..3 (64 columns), j = 4 (16)
+        park_constants();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mblk = mrow0 + i * 32;
+            const float rs = st_rs[i], rt = st_rt[i];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int j0 = c * 4, nj = c ? 1 : 4;
@@ -189,16 +275,16 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
                     const int j = j0 + jj;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int nb = gcol0 + j * 16 + 8 * q + 4 * hi;
+                        const int co = j * 16 + 8 * q + 4 * hi;         // column offset inside the wave's 80 outputs
                         float hv[4], gv[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             hv[e] = acc[j][i][4 * q + e] * alpha;
                             gv[e] = acc[j][i][8 + 4 * q + e] * alpha;
                         }
-                        if (rsp) {
-                            const f4v ch = *reinterpret_cast<const f4v*>(cvp + nb);
-                            const f4v cg = *reinterpret_cast<const f4v*>(cvp + Ni + nb);
+                        if constexpr (LN) {
+                            const f4v ch = *reinterpret_cast<const f4v*>(cst + 160 + co);
+                            const f4v cg = *reinterpret_cast<const f4v*>(cst + 240 + co);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 hv[e] = __builtin_fmaf(rs, hv[e], rt * ch[e]);
@@ -206,10 +292,10 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
                             }
                         }
                         if (bias) {
-                            const h4 bh = *reinterpret_cast<const h4*>(bias + nb);
-                            const h4 bg = *reinterpret_cast<const h4*>(bias + Ni + nb);
+                            const f4v bh = *reinterpret_cast<const f4v*>(cst + co);
+                            const f4v bg = *reinterpret_cast<const f4v*>(cst + 80 + co);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { hv[e] += (float)bh[e]; gv[e] += (float)bg[e]; }
+                            for (int e = 0; e < 4; ++e) { hv[e] += bh[e]; gv[e] += bg[e]; }
                         }
                         f4v o;
 #pragma unroll
@@ -218,46 +304,49 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
                     }
                     __builtin_amdgcn_sched_barrier(0);   // one accumulator tile at a time (register pressure)
                 }
-                if (c == 0) epilogue_rows<64>(p, stg, lane, mblk, gcol0, false);
-                else epilogue_rows<16>(p, stg, lane, mblk, gcol0 + 64, false);
+                if (c == 0) epilogue_rows<64, 0, false>(p, stg, lane, mblk, gcol0, nullptr, ps, nullptr, 0, 0);
+                else epilogue_rows<16, 0, false>(p, stg, lane, mblk, gcol0 + 64, nullptr, ps, nullptr, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            continue;
         }
+    } else {
         // plain: chunks j = {0, 1}, {2, 3} (64 columns: one full 128-byte line per row), {4} (32 columns)
-        float st_rs = 1.f, st_rt = 0.f;
-        if (p->rowscale) {
-            const unsigned mr = (unsigned)min(mblk + l31, (int)p->M - 1);
-            st_rs = p->rowscale[2 * mr];
-            st_rt = p->rowscale[2 * mr + 1];
-        }
+        const bool use_cst = LN || bias != nullptr;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int j0 = c * 2, nj = c < 2 ? 2 : 1;
-            const int stride = nj * 32 + 4;
+        for (int i = 0; i < TM; ++i) {
+            const int mblk = mrow0 + i * 32;
 #pragma unroll
-            for (int jj = 0; jj < nj; ++jj) {
+            for (int c = 0; c < 3; ++c) {
+                const int j0 = c * 2, nj = c < 2 ? 2 : 1;
+                const int stride = nj * 32 + 4;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f4v o;
+                for (int jj = 0; jj < nj; ++jj) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = acc[j0 + jj][i][4 * g + e] * alpha;
-                    *reinterpret_cast<f4v*>(stg + l31 * stride + jj * 32 + 8 * g + 4 * hi) = o;
+                    for (int g = 0; g < 4; ++g) {
+                        f4v o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[j0 + jj][i][4 * g + e] * alpha;
+                        *reinterpret_cast<f4v*>(stg + l31 * stride + jj * 32 + 8 * g + 4 * hi) = o;
+                    }
                 }
+                if (i == 0 && c == 0) park_constants();
+                __builtin_amdgcn_sched_barrier(0);
+                const float* cc_ = use_cst ? cst + c * 64 : nullptr;
+                if (c < 2) epilogue_rows<64, ADD ? PD : 0, LN>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + c * 4, NF, st_rs[i], st_rt[i]);
+                else epilogue_rows<32, ADD ? PD : 0, LN>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + 8, NF, st_rs[i], st_rt[i]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if (c < 2) epilogue_rows<64>(p, stg, lane, mblk, ncol0 + j0 * 32, true, st_rs, st_rt);
-            else epilogue_rows<32>(p, stg, lane, mblk, ncol0 + j0 * 32, true, st_rs, st_rt);
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 // TM: 32-row blocks per wave (tile = 128*TM x 320).  CONV: implicit-GEMM A loader (a_mode 1) or plain row-major A.
-// CUT1 / CUT2: this wave's 2*TM + 5 DMA pieces of a slab are issued in the load phases L0 [0, CUT1), L1 [CUT1, CUT2),
-// L2 [CUT2, ..) (A pieces first: they come from HBM / Infinity Cache, the weights from L2); L3 issues nothing.
-template <int TM, bool CONV, int CUT1, int CUT2>
+// EPI: epilogue kind (EPI_* bits).  This wave's 2*TM + 5 DMA pieces of a slab are issued in the load phases
+// L0 [0, CUT1), L1 [CUT1, CUT2), L2 [CUT2, ..) (A pieces first: they come from HBM / Infinity Cache, the weights from
+// L2); L3 issues nothing.  (Other cut points were measured in round 3 — profiles/r03_gemm_sched_ab_b2.txt — and dropped.)
+template <int TM, bool CONV, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused, const int tiles_total) {
+    constexpr int CUT1 = 3, CUT2 = TM == 2 ? 6 : 5;
     constexpr int TN = 5;
     constexpr int BM = 128 * TM, BN = 320;
     constexpr int WM = 32 * TM, WN = 160;
@@ -310,7 +399,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     const int flags = p->pp_flags;
     const bool blocked = (flags & PP_TILES_LINEAR) == 0;
     const int tiles_m = (Mi + BM - 1) / BM;
-    const int geglu = p->geglu;
+    constexpr bool geglu = (EPI & EPI_GEGLU) != 0;
     const int K = (int)p->K;
     const int nk = (K + BK - 1) / BK;
     const int ktail_from = K - (nk - 1) * BK;            // last slab: k offsets >= this are beyond K
@@ -556,8 +645,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             const int n0 = geglu ? tile_n * (BN / 2) : tile_n * BN;
             const int stg_off = wave < NFIT ? ((c_g - 1) & 1) * STAGE + wave * EP_BYTES
                                             : 2 * STAGE + (wave - NFIT) * EP_BYTES;
-            epilogue_pp<TM>(acc, reinterpret_cast<float*>(smem + stg_off), tile_m * BM + wr * WM, n0 + wc * WN,
-                            n0 + wc * TN * 16, lane);
+            constexpr int PD = (EPI & EPI_LN) ? 2 : (CONV ? 3 : 4);      // addend ring depth
+            epilogue_pp<TM, EPI, PD>(acc, reinterpret_cast<float*>(smem + stg_off), tile_m * BM + wr * WM, n0 + wc * WN,
+                                 n0 + wc * TN * 16, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         lgkm0();
@@ -567,14 +657,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     if (G == 0) bar();                          // matches group 1's extra barrier at the start
 }
 
-template <int TM, bool CONV, int CUT1, int CUT2>
+template <int TM, bool CONV, int EPI>
 int launch_one(const GemmParams& p, hipStream_t stream) {
     constexpr size_t stage = (size_t)(128 * TM + 320) * 128;
     constexpr size_t smem = 2 * stage + (8 - stage / EP_BYTES) * EP_BYTES;     // ring + the staging areas behind it
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TM, CONV, CUT1, CUT2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<TM, CONV, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -588,8 +678,7 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = p.tiles_total < n_cu ? p.tiles_total : n_cu;      // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm_pp_kernel<TM, CONV, CUT1, CUT2>), dim3((unsigned)grid), dim3(512), smem, stream, p,
-                       p.tiles_total);
+    hipLaunchKernelGGL((gemm_pp_kernel<TM, CONV, EPI>), dim3((unsigned)grid), dim3(512), smem, stream, p, p.tiles_total);
     return vsx_check_launch("vsx_gemm_f16 (persistent)");
 }
 
@@ -601,7 +690,10 @@ bool pp_supported(const GemmParams& p) {
     if (cols % 320 != 0 || p.c_mode != 0 || p.splitk > 1) return false;
     if (!p.vec8 || (p.residual && !p.rvec8)) return false;
     if (!vsx_aligned16(p.bias) || !vsx_aligned16(p.rowvec) || !vsx_aligned16(p.colvec)) return false;      // 16-byte epilogue loads
-    if (p.geglu && p.rowvec) return false;
+    // one prefetched addend: residual or row vector (not both; not under GEGLU); a 32-row block meets <= 2 row vectors
+    if (p.rowvec && (p.residual || p.geglu || p.rows_per_vec < 32)) return false;
+    if (p.geglu && p.residual) return false;
+    if (p.rowscale && p.a_mode == 1) return false;
     if (p.a_mode == 1) {
         const int ctot = p.C1 + p.C2;
         if (ctot % BK != 0 || p.C1 % BK != 0) return false;      // a slab must not straddle a tap or a source
@@ -614,21 +706,26 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     const long cols = p.geglu ? 2 * p.N : p.N;
     p.tiles_n = (int)(cols / 320);
     p.tiles_total = (int)(((p.M + bm - 1) / bm) * p.tiles_n);
-    // option "pp_sched" (env VSX_PP_SCHED) selects the piece schedule (cut points of the L0 | L1 | L2 split) among
-    // the compiled variants
-    const long opt = gemm_option("pp_sched");
-    const int variant = (int)(opt & 3);
-    p.pp_flags = (int)(opt & PP_TILES_LINEAR);
+    // option "pp_sched" (env VSX_PP_SCHED): PP_* bits (tile walk)
+    p.pp_flags = (int)(gemm_option("pp_sched") & PP_TILES_LINEAR);
     const bool conv = p.a_mode == 1;
-    if (bm == 256) {                            // 9 pieces per wave and slab
-        if (variant == 1) return conv ? launch_one<2, true, 4, 7>(p, stream) : launch_one<2, false, 4, 7>(p, stream);
-        if (variant == 2) return conv ? launch_one<2, true, 5, 9>(p, stream) : launch_one<2, false, 5, 9>(p, stream);
-        return conv ? launch_one<2, true, 3, 6>(p, stream) : launch_one<2, false, 3, 6>(p, stream);
-    }
-    // 7 pieces
-    if (variant == 1) return conv ? launch_one<1, true, 3, 6>(p, stream) : launch_one<1, false, 3, 6>(p, stream);
-    if (variant == 2) return conv ? launch_one<1, true, 4, 7>(p, stream) : launch_one<1, false, 4, 7>(p, stream);
-    return conv ? launch_one<1, true, 3, 5>(p, stream) : launch_one<1, false, 3, 5>(p, stream);
+    const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0);
+#define VSX_PP_CASE(TM_, CONV_, EPI_) \
+    if ((bm == 256) == (TM_ == 2) && conv == CONV_ && epi == (EPI_)) return launch_one<TM_, CONV_, (EPI_)>(p, stream);
+#define VSX_PP_CASES(TM_)                             \
+    VSX_PP_CASE(TM_, true, 0)                         \
+    VSX_PP_CASE(TM_, true, EPI_ADD)                   \
+    VSX_PP_CASE(TM_, false, 0)                        \
+    VSX_PP_CASE(TM_, false, EPI_ADD)                  \
+    VSX_PP_CASE(TM_, false, EPI_LN)                   \
+    VSX_PP_CASE(TM_, false, EPI_LN | EPI_ADD)         \
+    VSX_PP_CASE(TM_, false, EPI_GEGLU)                \
+    VSX_PP_CASE(TM_, false, EPI_GEGLU | EPI_LN)
+    VSX_PP_CASES(2)
+    VSX_PP_CASES(1)
+#undef VSX_PP_CASES
+#undef VSX_PP_CASE
+    return vsx_fail(VSX_E_UNSUPPORTED, "gemm_pp: no kernel for this epilogue (pp_supported must be asked first)");
 }
 
 }  // namespace vsxg
