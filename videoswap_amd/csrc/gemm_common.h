@@ -40,7 +40,9 @@ struct GemmParams {
 // other cut points of the DMA piece schedule (+-1 %), conv slab order "taps of a channel slab back to back" (8-13 %
 // slower: the per-slab address update runs on the VALU, which is blocked while the partner wave streams MFMAs), no
 // s_setprio / s_setprio on the LOAD phase (+-1 %), K-start stagger per workgroup (+5-9 % in tools/ubench/gemm_loop.hip,
-// -6 ... +10 % in the kernel: no net gain).
+// -6 ... +10 % in the kernel: no net gain), start-time stagger of the workgroups by quarters of a tile period, so that
+// the epilogues (HBM writes) of some CUs fall under the main loops of others (profiles/r03_gemm_stagger_ab_b2.txt: +-2 %
+// at K = 320, slower everywhere else: the CUs are not in lockstep to begin with).
 constexpr int PP_TILES_LINEAR = 8;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
