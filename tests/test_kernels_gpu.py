@@ -202,14 +202,14 @@ def both_gemm_paths(fn):
 
 
 def _sched(sched):
-    """piece schedule of the persistent kernel under test: the case's own, or VSX_TEST_PP_SCHED (a candidate schedule of
-    the development library, VSX_LIB_VARIANT=next) for every case"""
+    """pp_sched of the persistent kernel under test (8 = linear tile walk instead of the 2-D one): the case's own, or
+    VSX_TEST_PP_SCHED for every case"""
     import os
     return int(os.environ.get('VSX_TEST_PP_SCHED', sched))
 
 
 @pytest.mark.parametrize('M,N,K,res,sched', [
-    (65536, 320, 320, True, 0), (65536, 320, 1280, True, 1), (65536, 960, 320, False, 2), (61440, 640, 640, False, 0),
+    (65536, 320, 320, True, 0), (65536, 320, 1280, True, 8), (65536, 960, 320, False, 8), (61440, 640, 640, False, 0),
     (131072, 320, 320, True, 0), (8192, 1280, 1280, True, 0), (8192, 3840, 1280, False, 0), (32768, 640, 2560, True, 0),
     (65500, 320, 328, True, 0),      # ragged last M tile, K tail (328 = 5 slabs + 8)
     (5000, 640, 64, False, 0),       # one slab per tile: every stream element changes tile
@@ -239,28 +239,37 @@ def test_persistent_geglu(M, N, K):
     assert torch.equal(old, new)
 
 
+@pytest.mark.parametrize('addend', ['rowvec', 'residual', 'none'])
 @pytest.mark.parametrize('nimg,H,W,C1,C2,Cout,ks,stride,ups,sched', [
     (16, 64, 64, 320, 0, 320, 3, 1, False, 0),
-    (16, 64, 64, 320, 320, 320, 3, 1, False, 1),   # two sources
+    (16, 64, 64, 320, 320, 320, 3, 1, False, 8),   # two sources
     (16, 64, 64, 640, 320, 320, 1, 1, False, 0),   # 1x1 shortcut on a concat
-    (64, 64, 64, 320, 0, 640, 3, 2, False, 2),     # stride 2
+    (64, 64, 64, 320, 0, 640, 3, 2, False, 8),     # stride 2
     (16, 32, 32, 640, 0, 320, 3, 1, True, 0),      # nearest-2x upsample folded in
     (20, 56, 96, 320, 0, 320, 3, 1, False, 0),     # ragged M (107 520 rows), Wo = 96
     (32, 16, 16, 1280, 0, 1280, 3, 1, False, 0),   # M = 8192: 128x320 tiles
     (3, 28, 48, 128, 64, 640, 3, 1, False, 0),     # M = 4032 (not a multiple of 128), W = 48: 128x320 tiles
+    (100, 6, 8, 128, 0, 320, 3, 1, False, 0),      # 48 rows per image: 32-row blocks that meet two row vectors
 ])
-def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched):
+def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched, addend):
+    """The persistent kernel carries ONE addend through its epilogue ring (time-embedding row vector on a ResNet's first
+    convolution, residual on its second); both at once go to the tile kernels (covered by test_conv_*)."""
     x = rnd(nimg, H, W, C1, seed=97)
     x2 = rnd(nimg, H, W, C2, seed=98) if C2 else None
     Kc = ks * ks * (C1 + C2)
     w, b = rnd(Cout, ks, ks, C1 + C2, seed=99, scale=Kc ** -0.5), rnd(Cout, seed=100)
     Ho = (2 * H if ups else H) // stride
     Wo = (2 * W if ups else W) // stride
-    rowvec, res = rnd(nimg, Cout, seed=101), rnd(nimg, Ho, Wo, Cout, seed=102)
+    rowvec = rnd(nimg, Cout, seed=101) if addend == 'rowvec' else None
+    res = rnd(nimg, Ho, Wo, Cout, seed=102) if addend == 'residual' else None
     ops().set_option('pp_sched', _sched(sched))
     old, new = both_gemm_paths(lambda: ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec,
-                                                    rows_per_vec=Ho * Wo, residual=res))
-    ref = conv_ref(x, w, b, stride, x2, ups) + rowvec.float()[:, None, None, :] + res.float()
+                                                    rows_per_vec=Ho * Wo if rowvec is not None else 0, residual=res))
+    ref = conv_ref(x, w, b, stride, x2, ups)
+    if rowvec is not None:
+        ref = ref + rowvec.float()[:, None, None, :]
+    if res is not None:
+        ref = ref + res.float()
     assert rel_err(new, ref) < 2e-3
     if nimg * Ho * Wo >= 8192:       # (smaller problems take split-K on the tile-kernel side: other summation order)
         assert torch.equal(old, new)
