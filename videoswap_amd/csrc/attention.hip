@@ -431,6 +431,13 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempParams p) 
 }
 
 
+// V^T tile in LDS: row = channel, 32 keys + 8 pad halfs per row.  The scatter writes 2-byte elements; the row pitch (80 B) times
+// the 8 rows between two 16-byte channel groups is a multiple of the 128-byte bank period, so without a swizzle every channel
+// group of a key lands on the same bank (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.69 - 0.93 in profiles/r02_pmc_sq.txt).
+// The 8-key chunk of a row is XORed with the row's channel group (low two bits): channel groups spread over four chunk positions, and the
+// b128 fragment reads (one row per lane, 8 consecutive rows share the XOR) stay conflict-free.
+__device__ __forceinline__ int vt_col(const int key, const int chgroup) { return key ^ ((chgroup & 3) << 3); }
+
 // K8 on the matrix cores.  A (site, head) problem is only fq x fk x d (16 x 16 x 40): G = 32 / max(fq, fk) problems —
 // consecutive heads of one site — are packed along BOTH dimensions of a 32x32 tile, S^T[(g,key), (g',query)], and the
 // off-diagonal blocks (g != g') are masked to zero probability, which makes P block-diagonal so that one
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const TempParam
                 const int key = u / DV, ch = u - key * DV;
                 const h8 v = as_h8(raw[i]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sVT[(ch * 8 + e) * VSTR + key] = v[e];
+                for (int e = 0; e < 8; ++e) sVT[(ch * 8 + e) * VSTR + vt_col(key, ch)] = v[e];
             }
         }
     }
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const TempParam
         for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)sc[8 * s2 + jj];
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
-            const h8 vf = *reinterpret_cast<const h8*>(sVT + (t * 32 + l31) * VSTR + 16 * s2 + 8 * hi);
+            const h8 vf = *reinterpret_cast<const h8*>(sVT + (t * 32 + l31) * VSTR + vt_col(16 * s2 + 8 * hi, (t * 32 + l31) >> 3));
             o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
         }
     }
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_long_kernel(const Temp
                     const int kk = u / DV, ch = u - kk * DV;
                     const h8 v = as_h8(raw[i]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sVT[(ch * 8 + e) * VSTR + kk] = v[e];
+                    for (int e = 0; e < 8; ++e) sVT[(ch * 8 + e) * VSTR + vt_col(kk, ch)] = v[e];
                 }
             }
 #pragma unroll
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_long_kernel(const Temp
                 for (int jj = 0; jj < 8; ++jj) pf[jj] = g == qg ? (half_t)sc[kb][8 * s2 + jj] : (half_t)0.f;
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
-                    const h8 vf = *reinterpret_cast<const h8*>(sVT + (t * 32 + l31) * VSTR + 16 * s2 + 8 * hi);
+                    const h8 vf = *reinterpret_cast<const h8*>(sVT + (t * 32 + l31) * VSTR + vt_col(16 * s2 + 8 * hi, (t * 32 + l31) >> 3));
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
                 }
             }

@@ -514,7 +514,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             }
             return;
         }
-        // lane owns row m (column of the C^T tile); register quad g of tile (j, i) holds 4 consecutive columns
+        // lane owns row m (column of the C^T tile); register quad g of tile (j, i) holds 4 consecutive columns.
+        // The bias quads of the wave's full 32-column tiles are loaded HERE, all of them before the first store: a load
+        // issued between the stores of two tiles is waited for with vmcnt(0), i.e. together with the stores in flight
+        // (gemm_pp.hip has the measurements).  Small waves only (the register budget of the 16-wave kernel is 128).
+        constexpr bool PRE_BIAS = (NW <= 8) && (TM * TN <= 5);
+        h4 bpre[PRE_BIAS ? TN : 1][4];
+        const bool pre_bias = PRE_BIAS && p.bias != nullptr && p.vec8 && !p.geglu;
+        if constexpr (PRE_BIAS) {
+            if (pre_bias) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = nb0 + wc * WN + j * 32 + 8 * g + 4 * hi;
+                        bpre[j][g] = nb + 3 < Ni ? *reinterpret_cast<const h4*>(p.bias + nb) : h4{};
+                    }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = mb + wr * WM + i * 32 + l31;
@@ -624,7 +641,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(rs, o[e], rt * c[e]);
                         }
                         if (p.bias) {
-                            const h4 b = *reinterpret_cast<const h4*>(p.bias + nb);
+                            h4 b;
+                            if (PRE_BIAS && pre_bias) b = bpre[PRE_BIAS ? j : 0][g];
+                            else b = *reinterpret_cast<const h4*>(p.bias + nb);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }

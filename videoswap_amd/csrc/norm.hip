@@ -19,6 +19,14 @@ __host__ __device__ inline int gn_apply_rows(long rows, long nimg) {
     return (int)(r < 2 ? 2 : (r > 64 ? 64 : r));
 }
 
+// Per-thread partial sums of the statistics kernel in LDS: a thread owns 8 consecutive channels.  Scalar writes in channel order sit
+// at a pitch of 8 floats and use an eighth of the banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.75); channel c = 8 v + e is
+// kept at (e / 4) * C / 2 + 4 v + e % 4 instead, so that a thread writes two 16-byte quads and the low quads of all lanes are contiguous
+// (0.64: what is left comes from rows of 40 vectors wrapping inside the 16-lane groups of a b128 access).  Neither kernel is bound by
+// LDS (lds_issue_stall 0.01 - 0.06, both run at the rate of a device copy): the apply kernel keeps its channel-order tables — the
+// same remap there raised its ratio from 0.42 to 0.64 without changing its time (profiles/r03_pmc_sq_lds.txt).
+__device__ __forceinline__ int gn_col(const int c, const int C) { return ((c >> 2) & 1) * (C >> 1) + (c >> 3) * 4 + (c & 3); }
+
 __device__ __forceinline__ uint4 gn_load(const half_t* x1, const half_t* x2, long row, int c, int C1, int C2) {
     const half_t* ptr = (c < C1) ? x1 + row * C1 + c : x2 + row * C2 + (c - C1);     // one load, selected address
     return ld16(ptr);
@@ -28,8 +36,8 @@ __device__ __forceinline__ uint4 gn_load(const half_t* x1, const half_t* x2, lon
 __global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t* __restrict__ x1,
                                                                    const half_t* __restrict__ x2, long rows, int C1,
                                                                    int C2, int groups, float* __restrict__ partial) {
-    __shared__ float red_s[4096];
-    __shared__ float red_q[4096];
+    __shared__ __attribute__((aligned(16))) float red_s[4096];
+    __shared__ __attribute__((aligned(16))) float red_q[4096];
     const int C = C1 + C2;
     const int vpr = C >> 3;                   // vectors per row (<= 512)
     const int rp = GN_STAT_THREADS / vpr;      // rows per pass (>= 1)
@@ -65,24 +73,26 @@ __global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t*
                 }
             }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            red_s[rl * C + cv * 8 + e] = s[e];
-            red_q[rl * C + cv * 8 + e] = q[e];
-        }
+        // a thread's 8 channels go out as two 16-byte writes, the low quads of a row's threads contiguous, then the high quads
+        // (scalar writes at a pitch of 8 floats hit 4 of the 32 banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.75)
+        *reinterpret_cast<f4v*>(red_s + rl * C + cv * 4) = f4v{s[0], s[1], s[2], s[3]};
+        *reinterpret_cast<f4v*>(red_s + rl * C + (C >> 1) + cv * 4) = f4v{s[4], s[5], s[6], s[7]};
+        *reinterpret_cast<f4v*>(red_q + rl * C + cv * 4) = f4v{q[0], q[1], q[2], q[3]};
+        *reinterpret_cast<f4v*>(red_q + rl * C + (C >> 1) + cv * 4) = f4v{q[4], q[5], q[6], q[7]};
     }
     __syncthreads();
     for (int c = tid; c < C; c += GN_STAT_THREADS) {
+        const int col = gn_col(c, C);           // the column sum stays in its (permuted) column of row 0
         float a = 0.f, b = 0.f;
-        for (int r = 0; r < rp; ++r) { a += red_s[r * C + c]; b += red_q[r * C + c]; }
-        red_s[c] = a;
-        red_q[c] = b;
+        for (int r = 0; r < rp; ++r) { a += red_s[r * C + col]; b += red_q[r * C + col]; }
+        red_s[col] = a;
+        red_q[col] = b;
     }
     __syncthreads();
     if (tid < groups) {
         const int cpg = C / groups;
         float a = 0.f, b = 0.f;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += red_s[c]; b += red_q[c]; }
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += red_s[gn_col(c, C)]; b += red_q[gn_col(c, C)]; }
         float* out = partial + ((img * gridDim.x + chunk) * groups + tid) * 2;
         out[0] = a;
         out[1] = b;
