@@ -43,20 +43,50 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 // v_exp + v_rcp (1 ulp) instead of an IEEE division: the result is rounded to fp16 anyway
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output rounding): one v_rcp, one v_exp
-// and five FMAs instead of the ~40-instruction libm erff — the GEGLU epilogue evaluates it once per output element
-__device__ __forceinline__ float erf_fast(float x) {
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) by Abramowitz & Stegun 7.1.28, erf z = 1 - (1 + a1 z + ... + a6 z^6)^-16 (|error| <= 3e-7,
+// far below the fp16 output rounding; the sqrt 2 is folded into the coefficients): six FMAs, four squarings and ONE
+// transcendental.  The GEGLU epilogue evaluates it once per output element and is bound by VALU issue; the first fast form
+// (7.1.26: one v_rcp AND one v_exp, each a quarter-rate instruction) spent half of its cycles in the two of them.
+__device__ __forceinline__ float norm_cdf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float e = 1.0f - poly * t * __expf(-ax * ax);
-    return copysignf(e, x);
+    float p = 5.3829750000e-06f;
+    p = __builtin_fmaf(p, ax, 4.8890635643e-05f);
+    p = __builtin_fmaf(p, ax, 3.8003575000e-05f);
+    p = __builtin_fmaf(p, ax, 3.2776263241e-03f);
+    p = __builtin_fmaf(p, ax, 2.1141006150e-02f);
+    p = __builtin_fmaf(p, ax, 4.9867346967e-02f);
+    p = __builtin_fmaf(p, ax, 1.0f);
+    p *= p;
+    p *= p;
+    p *= p;
+    p *= p;                                                     // overflows to +inf beyond |x| ~ 21: rcp -> 0
+    const float hr = 0.5f * __builtin_amdgcn_rcpf(p);           // 0.5 (1 - erf(|x| / sqrt 2)), relative accuracy ~1e-6
+    return x < 0.f ? hr : 1.0f - hr;
 }
-__device__ __forceinline__ float gelu_erf_f(float x) {
-    return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+// Two at a time, written on 2-vectors so that the FMAs, squarings and the final combination become packed-fp32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth per issue slot): gelu(x) = 0.5 x + |x| (0.5 - hr) with hr as above — no
+// compare, no select.  Every GEGLU path (persistent and tile kernels, vsx_geglu_fwd) evaluates this form, so they agree bit for bit.
+typedef float vsx_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vsx_f2 gelu_erf_f2(vsx_f2 x) {
+    vsx_f2 ax;
+    ax[0] = fabsf(x[0]);
+    ax[1] = fabsf(x[1]);
+    vsx_f2 p = 5.3829750000e-06f;
+    p = p * ax + 4.8890635643e-05f;
+    p = p * ax + 3.8003575000e-05f;
+    p = p * ax + 3.2776263241e-03f;
+    p = p * ax + 2.1141006150e-02f;
+    p = p * ax + 4.9867346967e-02f;
+    p = p * ax + 1.0f;
+    p *= p;
+    p *= p;
+    p *= p;
+    p *= p;
+    vsx_f2 r;
+    r[0] = __builtin_amdgcn_rcpf(p[0]);
+    r[1] = __builtin_amdgcn_rcpf(p[1]);
+    const vsx_f2 w = r * -0.5f + 0.5f;                          // 0.5 - hr = 0.5 erf(|x| / sqrt 2)
+    return ax * w + x * 0.5f;
 }
+__device__ __forceinline__ float gelu_erf_f(float x) { return gelu_erf_f2(vsx_f2{x, x})[0]; }   // same arithmetic (edge paths)
 #endif

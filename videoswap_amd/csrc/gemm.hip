@@ -572,9 +572,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { hv[e] += (float)bh[e]; gv[e] += (float)bg[e]; }
                             }
-                            float o[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
+                            const vsx_f2 g01 = gelu_erf_f2(vsx_f2{gv[0], gv[1]}), g23 = gelu_erf_f2(vsx_f2{gv[2], gv[3]});
+                            float o[4] = {hv[0] * g01[0], hv[1] * g01[1], hv[2] * g23[0], hv[3] * g23[1]};
                             if (rrow) {
                                 const h4 b = *reinterpret_cast<const h4*>(rrow + nb);
 #pragma unroll

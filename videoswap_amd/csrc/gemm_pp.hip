@@ -297,9 +297,8 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { hv[e] += bh[e]; gv[e] += bg[e]; }
                         }
-                        f4v o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = hv[e] * gelu_erf_f(gv[e]);
+                        const vsx_f2 g01 = gelu_erf_f2(vsx_f2{gv[0], gv[1]}), g23 = gelu_erf_f2(vsx_f2{gv[2], gv[3]});
+                        const f4v o = {hv[0] * g01[0], hv[1] * g01[1], hv[2] * g23[0], hv[3] * g23[1]};
                         *reinterpret_cast<f4v*>(stg + l31 * stride + jj * 16 + 8 * q + 4 * hi) = o;
                     }
                     __builtin_amdgcn_sched_barrier(0);   // one accumulator tile at a time (register pressure)

@@ -23,7 +23,7 @@ constexpr int TR_THREADS = 256;
 
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // Phi(x) and phi(x) of the standard normal: gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x)
-__device__ __forceinline__ float norm_cdf(float x) { return 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float norm_cdf(float x) { return norm_cdf_fast(x); }
 __device__ __forceinline__ float norm_pdf(float x) { return 0.3989422804014327f * __expf(-0.5f * x * x); }
 
 __device__ __forceinline__ float block_sum(float v, float* red) {      // red: >= TR_THREADS / 64 floats of LDS
@@ -49,7 +49,11 @@ __global__ void geglu_fwd_kernel(const half_t* __restrict__ y2, half_t* __restri
     const h8 g = as_h8(ld16(y2 + m * 2 * N + N + c));
     h8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)h[e] * gelu_erf_f((float)g[e]));
+    for (int e = 0; e < 8; e += 2) {
+        const vsx_f2 v = gelu_erf_f2(vsx_f2{(float)g[e], (float)g[e + 1]});
+        o[e] = (half_t)((float)h[e] * v[0]);
+        o[e + 1] = (half_t)((float)h[e + 1] * v[1]);
+    }
     st16(out + m * N + c, as_u4(o));
 }
 
