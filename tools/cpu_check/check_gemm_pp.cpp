@@ -142,7 +142,8 @@ static void run_case(const Case& c) {
 }
 
 // 3x3 convolution (implicit GEMM, two concatenated sources, optional stride 2 / nearest-2x input) + bias + row vector
-static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, int Cout, int stride, int ups, int bm) {
+static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, int Cout, int stride, int ups, int bm,
+                     bool with_rowvec = true) {
     using namespace vsxg;
     const int ks = 3, pad = 1;
     const int Hs = ups ? H / 2 : H, Ws = ups ? W / 2 : W;               // stored resolution of the sources
@@ -155,7 +156,7 @@ static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, i
         for (int ho = 0; ho < Ho; ++ho)
             for (int wo = 0; wo < Wo; ++wo)
                 for (int co = 0; co < Cout; ++co) {
-                    double s = (double)bias[co] + (double)rowvec[(size_t)i * Cout + co];
+                    double s = (double)bias[co] + (with_rowvec ? (double)rowvec[(size_t)i * Cout + co] : 0.0);
                     for (int kh = 0; kh < ks; ++kh)
                         for (int kw = 0; kw < ks; ++kw) {
                             const int h = ho * stride - pad + kh, w = wo * stride - pad + kw;
@@ -173,7 +174,7 @@ static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, i
         std::vector<half_t> C((size_t)M * Cout, (half_t)-7.f);
         GemmParams p{};
         p.A = X1.data(); p.A2 = C2 ? X2.data() : nullptr; p.B = Wt.data(); p.C = C.data();
-        p.bias = bias.data(); p.rowvec = rowvec.data(); p.rows_per_vec = (long)Ho * Wo;
+        p.bias = bias.data(); p.rowvec = with_rowvec ? rowvec.data() : nullptr; p.rows_per_vec = with_rowvec ? (long)Ho * Wo : 1;
         p.M = M; p.N = Cout; p.K = K; p.ldb = K; p.ldc = Cout; p.batch1 = 1; p.alpha = 1.0f;
         p.a_mode = 1; p.H = H; p.W = W; p.C1 = C1; p.C2 = C2; p.Ho = Ho; p.Wo = Wo; p.ks = ks; p.stride = stride;
         p.ups = ups; p.pad = pad;
@@ -218,6 +219,9 @@ int main(int argc, char** argv) {
         {"rowscale geglu 300x160x64 128-row", 300, 160, 64, false, true, 128, true},
         {"rowscale 700x320x64", 700, 320, 64, false, false, 256, true},                  // LayerNorm identity alone
         {"rowscale 200x640x128 (+res) 128-row", 200, 640, 128, true, false, 128, true},
+        {"plain 300x320x64 128-row", 300, 320, 64, false, false, 128},                  // the remaining kernel kinds
+        {"rowscale 300x320x64 128-row", 300, 320, 64, false, false, 128, true},
+        {"rowscale geglu 512x160x64", 512, 160, 64, false, true, 256, true},
     };
     // usage: check_gemm_pp [case index | -1 = all] [comma-separated schedules]
     cpuhip_num_cus = 24;                  // three workgroups per emulated XCD: blockIdx.x >> 3 takes the values 0, 1, 2
@@ -235,6 +239,8 @@ int main(int argc, char** argv) {
     if (only < 0 || only == ncases + 3) run_conv("conv3x3 1x16x16 128+64->320", 1, 16, 16, 128, 64, 320, 1, 0, 256);
     if (only < 0 || only == ncases + 4)      // 48 rows per vector: 32-row blocks that meet two row vectors
         run_conv("conv3x3 3x6x8 64->320", 3, 6, 8, 64, 0, 320, 1, 0, 256);
+    if (only < 0 || only == ncases + 5) run_conv("conv3x3 2x8x8 64->320, bias only", 2, 8, 8, 64, 0, 320, 1, 0, 256, false);
+    if (only < 0 || only == ncases + 6) run_conv("conv3x3 2x8x8 64->320, bias only, 128-row", 2, 8, 8, 64, 0, 320, 1, 0, 128, false);
     if (only < 0) {          // the 2-D tile walk visits every tile exactly once (any tile count, ragged last super-row)
         int bad = 0;
         for (int tn : {1, 2, 6, 8, 12, 16, 24, 32, 40, 44})
