@@ -28,6 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# what the power-managed clock sustains with all 256 CUs streaming MFMAs: 1.75 of 2.4 GHz (profiles/r03_ubench_clock_probe.txt);
+# reported beside the nominal peak, never instead of it
+MFMA_SUSTAINED_TFLOPS = 1820.0
 FRAME_EVAL_TFLOP = 1.1046     # algorithmic TFLOP of one frame-evaluation at T=16, 64x64
 
 
@@ -336,6 +339,8 @@ def main():
         out['roofline'] = {'bound': 'mfma', 'kernel': 'vsx_gemm_f16 (implicit-GEMM conv + GEMM, all shapes)',
                            'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_note,
+                           'peak_sustained': MFMA_SUSTAINED_TFLOPS, 'frac_of_sustained': round(ach / MFMA_SUSTAINED_TFLOPS, 4),
+                           'peak_sustained_source': 'core clock 1.75 GHz under chip-wide MFMA load (tools/ubench/clock_probe.hip)',
                            'launches_sampled': int(n_launch), 'sample_stride': args.prof_stride,
                            'sampling': ('all GEMM launches of every %d-th UNet call (eager); the other calls are '
                                         'HIP-graph replays' % args.prof_stride) if graphs else
