@@ -73,3 +73,29 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
                        env=dict(os.environ, CPUHIP_DMA='late'))
     print(r.stdout)
     assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
+    """vsx_gemm_f16 itself — descriptor checks, dispatch, the workgroup-per-tile kernels of csrc/gemm.hip (row-per-lane epilogue
+    with the permlane32 exchange, prefetched residual and bias quads, GEGLU, the transposed V^T store), split-K with its combine
+    kernel, the LayerNorm fold in every one of them, batched and convolution loaders — compiled from the real sources for the
+    host and compared with double-precision references (tools/cpu_check/check_gemm_api.cpp).  VSX_TUNE_TILE forces the
+    128x320 / 128x160 / 256x320 tile kernels, which problems this small would never reach through the dispatch."""
+    cxx = CXX if os.path.isfile(CXX) else shutil.which('clang++')
+    src = os.path.join(ROOT, 'tools', 'cpu_check')
+    exe = str(tmp_path / 'check_gemm_api')
+    cmd = [cxx, '-std=c++20', '-O1', '-pthread', '-I', src, '-I', os.path.join(ROOT, 'include'), '-I',
+           os.path.join(ROOT, 'videoswap_amd', 'csrc'), '-Wno-unused-function', '-Wno-unused-value', '-o', exe,
+           os.path.join(src, 'check_gemm_api.cpp')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = {k: v for k, v in os.environ.items() if k not in ('VSX_TUNE_TILE', 'VSX_GEMM_PP', 'VSX_PP_SCHED')}
+    for case in [str(c) for c in range(13)] + ['14', '15', '16', '17', '18']:      # (13: the persistent kernel, covered above)
+        r = subprocess.run([exe, case], capture_output=True, text=True, timeout=600, env=env)
+        print(r.stdout)
+        assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    for tile in ('1', '2', '3'):
+        for case in ('0', '1', '4', '7', '8', '10', '17'):
+            r = subprocess.run([exe, case], capture_output=True, text=True, timeout=600, env=dict(env, VSX_TUNE_TILE=tile))
+            print('VSX_TUNE_TILE=' + tile, r.stdout)
+            assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -1,0 +1,263 @@
+// Runs vsx_gemm_f16 — the C-ABI entry point with its shape checks, dispatch, the workgroup-per-tile kernels (gemm.hip), the
+// persistent kernel (gemm_pp.hip) and the split-K combine — on the CPU from the real sources, and compares every case with a
+// double-precision GEMM / convolution.  What check_gemm_pp.cpp is for the persistent kernel alone, this is for the whole
+// entry point: dispatch thresholds, tile-kernel epilogues (row-per-lane layout, permlane32 exchange, prefetched residual and
+// bias), GEGLU, the transposed V^T store, split-K + combine, the LayerNorm fold.  See hip_gemm.h for what the emulation
+// covers and what it cannot (asynchronous ordering of the LDS-DMA, register pressure, speed).
+#define CPUHIP_DYNAMIC_LDS_ONLY
+#include "hip/hip_runtime.h"
+#include "hip_gemm.h"
+
+#include <stdarg.h>
+
+// ---- pieces of the HIP runtime / gfx950 builtins only gemm.hip needs ----
+struct uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline long long clock64() { return 0; }
+// v_permlane32_swap: lanes 32-63 of `vdst` trade places with lanes 0-31 of `src`; returns (new vdst, new src)
+struct cpuhip_u2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+static inline cpuhip_u2 cpuhip_permlane32_swap(unsigned vdst, unsigned src) {
+    unsigned* s = static_cast<unsigned*>(cpuhip::ctx.wave_scratch);          // [0..63] vdst, [64..127] src
+    const int l = (int)(cpuhip::ctx.tid.x & 63);
+    s[l] = vdst;
+    s[64 + l] = src;
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    cpuhip_u2 r;
+    r.v[0] = l >= 32 ? s[64 + l - 32] : vdst;
+    r.v[1] = l < 32 ? s[l + 32] : src;
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    return r;
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) cpuhip_permlane32_swap(a, b)
+
+#include "common.h"
+
+int vsx_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "\n");
+    return code;
+}
+int vsx_check_launch(const char*) { return 0; }
+
+#include "gemm_common.h"
+namespace vsxg {
+namespace {
+CPUHIP_DEFINE_LDS
+}
+}
+#include "gemm_pp.hip"
+namespace {
+CPUHIP_DEFINE_LDS
+}
+#include "gemm.hip"
+
+
+static unsigned rng_state = 4242u;
+static float frand() {
+    rng_state = rng_state * 1664525u + 1013904223u;
+    return (float)((rng_state >> 8) & 0xFFFF) / 32768.0f - 1.0f;
+}
+static std::vector<half_t> randh(size_t n, float scale = 1.0f) {
+    std::vector<half_t> v(n);
+    for (auto& x : v) x = (half_t)(frand() * scale);
+    return v;
+}
+static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
+static int n_bad = 0;
+
+static void report(const char* name, int rc, const std::vector<double>& want, const std::vector<half_t>& got, double tol = 3e-3) {
+    double num = 0, den = 0;
+    for (size_t i = 0; i < want.size(); ++i) {
+        const double d = (double)got[i] - want[i];
+        num += d * d;
+        den += want[i] * want[i];
+    }
+    const double rel = sqrt(num / (den > 0 ? den : 1));
+    const bool ok = rc == 0 && rel < tol && cpuhip_oob_reads == 0;
+    printf("%-58s rc %d rel-L2 %.2e %s%s\n", name, rc, rel, cpuhip_oob_reads ? "reads past a tensor " : "", ok ? "ok" : "FAIL");
+    if (!ok) ++n_bad;
+    cpuhip_oob_reads = 0;
+}
+
+struct Plain {
+    const char* name;
+    long M, N, K;
+    bool res, rowvec, geglu, ln, vt;
+    long rows_per_vec, rows_per_img;
+    long pp;                // option gemm_pp for this case (0: tile kernels, 2: persistent kernel where eligible)
+    bool splitk;
+};
+
+// plain GEMM through the public entry point, every epilogue kind of the descriptor
+static std::vector<half_t> run_plain(const Plain& c, bool check = true) {
+    const long brows = c.geglu ? 2 * c.N : c.N;
+    auto A = randh((size_t)c.M * c.K), B = randh((size_t)brows * c.K, 1.0f / sqrtf((float)c.K)), bias = randh(brows);
+    auto R = randh((size_t)c.M * c.N);
+    const long nvec = c.rowvec ? (c.M + c.rows_per_vec - 1) / c.rows_per_vec : 1;
+    auto RV = randh((size_t)nvec * c.N);
+    std::vector<float> rowscale(2 * c.M), colvec(brows);
+    for (long m = 0; m < c.M; ++m) { rowscale[2 * m] = 0.5f + 0.01f * (float)(m % 37); rowscale[2 * m + 1] = -0.3f + 0.02f * (float)(m % 11); }
+    for (long n = 0; n < brows; ++n) { double s = 0; for (long k = 0; k < c.K; ++k) s += (double)B[n * c.K + k]; colvec[n] = (float)s; }
+    auto dot = [&](long m, long row) {
+        double s = 0;
+        for (long k = 0; k < c.K; ++k) s += (double)A[m * c.K + k] * (double)B[row * c.K + k];
+        if (c.ln) s = (double)rowscale[2 * m] * s + (double)rowscale[2 * m + 1] * (double)colvec[row];
+        return s + (double)bias[row];
+    };
+    const long nimg = c.vt ? c.M / c.rows_per_img : 1;
+    std::vector<double> want((size_t)c.M * c.N);
+    for (long m = 0; m < c.M; ++m)
+        for (long n = 0; n < c.N; ++n) {
+            double v = c.geglu ? dot(m, n) * gelu(dot(m, c.N + n)) : dot(m, n);
+            if (c.rowvec) v += (double)RV[(m / c.rows_per_vec) * c.N + n];
+            if (c.res) v += (double)R[m * c.N + n];
+            const size_t at = c.vt ? ((size_t)(m / c.rows_per_img) * c.N + n) * c.rows_per_img + m % c.rows_per_img : (size_t)m * c.N + n;
+            want[at] = v;
+        }
+    std::vector<half_t> C((size_t)c.M * c.N, (half_t)-7.f);
+    vsx_gemm_desc d{};
+    d.M = c.M; d.N = c.N; d.K = c.K; d.batch0 = d.batch1 = 1;
+    d.A = A.data(); d.lda = c.K; d.B = B.data(); d.ldb = c.K; d.C = C.data();
+    d.ldc = c.vt ? c.rows_per_img : c.N;
+    d.c_mode = c.vt ? 1 : 0; d.c_rows_per_img = c.vt ? c.rows_per_img : 0; d.c_img_stride = c.vt ? c.N * c.rows_per_img : 0;
+    d.bias = bias.data();
+    if (c.rowvec) { d.rowvec = RV.data(); d.rows_per_vec = c.rows_per_vec; }
+    if (c.res) { d.residual = R.data(); d.ldr = c.N; }
+    d.geglu = c.geglu; d.alpha = 1.0; d.pad_lo = d.pad_hi = -1;
+    if (c.ln) { d.rowscale = rowscale.data(); d.colvec = colvec.data(); }
+    std::vector<float> ws;
+    if (c.splitk) {
+        const int64_t bytes = vsx_gemm_workspace(&d);
+        if (bytes <= 0) { printf("%-58s no split-K plan FAIL\n", c.name); ++n_bad; }
+        ws.resize((size_t)bytes / 4 + 4);
+        d.workspace = ws.data(); d.workspace_bytes = bytes;
+    }
+    (void)nimg;
+    vsx_set_option("gemm_pp", c.pp);
+    const int rc = vsx_gemm_f16(&d, nullptr);
+    if (check) report(c.name, rc, want, C);
+    return C;
+}
+
+// batched GEMM (attention scores: A [b0, b1, M, K], B [b0, b1, N, K])
+static void run_batched(const char* name, long b0, long b1, long M, long N, long K) {
+    const long nb = b0 * b1;
+    auto A = randh((size_t)nb * M * K), B = randh((size_t)nb * N * K, 1.0f / sqrtf((float)K));
+    std::vector<double> want((size_t)nb * M * N);
+    for (long z = 0; z < nb; ++z)
+        for (long m = 0; m < M; ++m)
+            for (long n = 0; n < N; ++n) {
+                double s = 0;
+                for (long k = 0; k < K; ++k) s += (double)A[(z * M + m) * K + k] * (double)B[(z * N + n) * K + k];
+                want[(z * M + m) * N + n] = 0.125 * s;
+            }
+    std::vector<half_t> C((size_t)nb * M * N, (half_t)-7.f);
+    vsx_gemm_desc d{};
+    d.M = M; d.N = N; d.K = K; d.batch0 = b0; d.batch1 = b1;
+    d.A = A.data(); d.lda = K; d.a_bs1 = M * K; d.a_bs0 = b1 * M * K;
+    d.B = B.data(); d.ldb = K; d.b_bs1 = N * K; d.b_bs0 = b1 * N * K;
+    d.C = C.data(); d.ldc = N; d.c_bs1 = M * N; d.c_bs0 = b1 * M * N;
+    d.alpha = 0.125; d.pad_lo = d.pad_hi = -1;
+    vsx_set_option("gemm_pp", 1);
+    report(name, vsx_gemm_f16(&d, nullptr), want, C);
+}
+
+// 3x3 / 1x1 convolution with bias + time-embedding row vector + residual (both addends: the tile kernels)
+static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, int Cout, int ks, int stride, int ups, bool splitk) {
+    const int pad = ks / 2;
+    const int Hs = ups ? H / 2 : H, Ws = ups ? W / 2 : W;
+    const int Ho = (H + 2 * pad - ks) / stride + 1, Wo = (W + 2 * pad - ks) / stride + 1;
+    const long M = (long)nimg * Ho * Wo, K = (long)ks * ks * (C1 + C2);
+    auto X1 = randh((size_t)nimg * Hs * Ws * C1), X2 = randh((size_t)nimg * Hs * Ws * (C2 ? C2 : 1));
+    auto Wt = randh((size_t)Cout * K, 1.0f / sqrtf((float)K)), bias = randh(Cout), rowvec = randh((size_t)nimg * Cout);
+    auto R = randh((size_t)M * Cout);
+    std::vector<double> want((size_t)M * Cout);
+    for (int i = 0; i < nimg; ++i)
+        for (int ho = 0; ho < Ho; ++ho)
+            for (int wo = 0; wo < Wo; ++wo)
+                for (int co = 0; co < Cout; ++co) {
+                    const size_t at = ((size_t)(i * Ho + ho) * Wo + wo) * Cout + co;
+                    double s = (double)bias[co] + (double)rowvec[(size_t)i * Cout + co] + (double)R[at];
+                    for (int kh = 0; kh < ks; ++kh)
+                        for (int kw = 0; kw < ks; ++kw) {
+                            const int h = ho * stride - pad + kh, w = wo * stride - pad + kw;
+                            if (h < 0 || h >= H || w < 0 || w >= W) continue;
+                            const int hs = ups ? h / 2 : h, wsrc = ups ? w / 2 : w;
+                            const half_t* wrow = Wt.data() + (size_t)co * K + (size_t)(kh * ks + kw) * (C1 + C2);
+                            const size_t pix = ((size_t)i * Hs + hs) * Ws + wsrc;
+                            for (int c = 0; c < C1; ++c) s += (double)X1[pix * C1 + c] * (double)wrow[c];
+                            for (int c = 0; c < C2; ++c) s += (double)X2[pix * C2 + c] * (double)wrow[C1 + c];
+                        }
+                    want[at] = s;
+                }
+    std::vector<half_t> C((size_t)M * Cout, (half_t)-7.f);
+    vsx_gemm_desc d{};
+    d.M = M; d.N = Cout; d.K = K; d.batch0 = d.batch1 = 1;
+    d.A = X1.data(); d.A2 = C2 ? X2.data() : nullptr; d.a_mode = 1; d.H = H; d.W = W; d.C1 = C1; d.C2 = C2; d.ks = ks; d.stride = stride;
+    d.upsample = ups;
+    d.B = Wt.data(); d.ldb = K; d.C = C.data(); d.ldc = Cout;
+    d.bias = bias.data(); d.rowvec = rowvec.data(); d.rows_per_vec = (long)Ho * Wo; d.residual = R.data(); d.ldr = Cout;
+    d.alpha = 1.0; d.pad_lo = d.pad_hi = -1;
+    std::vector<float> ws;
+    if (splitk) {
+        const int64_t bytes = vsx_gemm_workspace(&d);
+        if (bytes <= 0) { printf("%-58s no split-K plan FAIL\n", name); ++n_bad; }
+        ws.resize((size_t)bytes / 4 + 4);
+        d.workspace = ws.data(); d.workspace_bytes = bytes;
+    }
+    vsx_set_option("gemm_pp", 1);
+    report(name, vsx_gemm_f16(&d, nullptr), want, C);
+}
+
+int main(int argc, char** argv) {
+    // usage: check_gemm_api [case | -1 = all]; VSX_TUNE_TILE=1|2|3 in the environment forces the 128x320 / 128x160 / 256x320
+    // tile kernel for the 320-column cases (the only way to reach them with problems this small)
+    cpuhip_num_cus = 8;
+    const int only = argc > 1 ? atoi(argv[1]) : -1;
+    const Plain plain[] = {
+        //  name                                              M    N    K   res  rowvec geglu ln    vT   rpv rpi pp splitK
+        {"plain 200x320x128 +res (tile)",                    200, 320, 128, true, false, false, false, false, 0, 0, 0, false},
+        {"plain 200x320x128 +rowvec +res (tile)",            200, 320, 128, true, true, false, false, false, 48, 0, 0, false},
+        {"narrow 100x96x72 (64x64 tile, K tail, ragged N)",  100, 96, 72, true, false, false, false, false, 0, 0, 0, false},
+        {"narrow 70x44x64 (scalar column edge)",             70, 44, 64, false, false, false, false, false, 0, 0, 0, false},
+        {"geglu 150x160x64 (tile)",                          150, 160, 64, false, false, true, false, false, 0, 0, 0, false},
+        {"geglu 90x48x64 (64x128 tile)",                     90, 48, 64, false, false, true, false, false, 0, 0, 0, false},
+        {"V^T store 256x80x64, 128 rows per image",          256, 80, 64, false, false, false, false, true, 0, 128, 0, false},
+        {"LayerNorm fold 200x320x128 (tile)",                200, 320, 128, false, false, false, true, false, 0, 0, 0, false},
+        {"LayerNorm fold geglu 150x160x64 (tile)",           150, 160, 64, false, false, true, true, false, 0, 0, 0, false},
+        {"LayerNorm fold V^T 256x80x64",                     256, 80, 64, false, false, false, true, true, 0, 128, 0, false},
+        {"LayerNorm fold + PE row vector 192x320x64",        192, 320, 64, false, true, false, true, false, 32, 0, 0, false},
+        {"split-K 128x320x1536 +res",                        128, 320, 1536, true, false, false, false, false, 0, 0, 0, true},
+        {"split-K LayerNorm fold 100x320x1536",              100, 320, 1536, false, false, false, true, false, 0, 0, 0, true},
+    };
+    const int nplain = (int)(sizeof(plain) / sizeof(plain[0]));
+    for (int i = 0; i < nplain; ++i)
+        if (only < 0 || only == i) run_plain(plain[i]);
+    if (only < 0 || only == nplain) {      // the persistent kernel through the entry point: bit for bit like the tile kernels
+        Plain c = {"persistent 4096x320x64 +res vs tile kernels", 4096, 320, 64, true, false, false, false, false, 0, 0, 0, false};
+        rng_state = 99u;
+        const auto a = run_plain(c, false);
+        c.pp = 2;
+        rng_state = 99u;
+        const auto b = run_plain(c, true);
+        const bool same = memcmp(a.data(), b.data(), a.size() * sizeof(half_t)) == 0;
+        printf("%-58s %s\n", "  ... bit-identical to gemm_pp = 0", same ? "ok" : "FAIL");
+        n_bad += same ? 0 : 1;
+    }
+    if (only < 0 || only == nplain + 1) run_batched("batched 2x3 x (40x56x40) scores", 2, 3, 40, 56, 40);
+    if (only < 0 || only == nplain + 2) run_conv("conv3x3 2x8x8 64+64->320 +rowvec +res", 2, 8, 8, 64, 64, 320, 3, 1, 0, false);
+    if (only < 0 || only == nplain + 3) run_conv("conv3x3 1x12x8 72->96 /s2 (narrow tiles)", 1, 12, 8, 72, 0, 96, 3, 2, 0, false);
+    if (only < 0 || only == nplain + 4) run_conv("conv1x1 2x8x8 128->320 nearest-2x", 2, 8, 8, 128, 0, 320, 1, 1, 1, false);
+    if (only < 0 || only == nplain + 5) run_conv("conv3x3 split-K 1x8x8 192->320", 1, 8, 8, 192, 0, 320, 3, 1, 0, true);
+    printf(n_bad ? "%d check(s) FAILED\n" : "all checks passed\n", n_bad);
+    return n_bad ? 1 : 0;
+}

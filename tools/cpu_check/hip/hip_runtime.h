@@ -4,7 +4,7 @@
 // A workgroup runs as blockDim.x OS threads (blocks one after the other); __syncthreads is a std::barrier over the
 // workgroup, __shfl_xor an exchange through a per-wave scratch array between two wave barriers (all 64 lanes of a wave
 // must call it, as on the hardware), __shared__ is static storage (one workgroup is alive at a time).
-// Used by tools/cpu_check/check_train.cpp only; never part of a library.
+// Used by tools/cpu_check/check_*.cpp only (with hip_gemm.h for the MFMA / LDS-DMA kernels); never part of a library.
 #pragma once
 #include <math.h>
 #include <stdint.h>
