@@ -53,16 +53,13 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     runs = [('0', '0,8'),                        # one 256x320 tile, one slab
             ('4', '0'),                          # GEGLU epilogue
-            ('6', '0'),                          # 128-row tiles, GEGLU, ragged M
             ('7', '0,8'),                        # 36 tiles, tiles_n = 12: the 2-D walk against the linear one
             ('8', '0'),                          # LayerNorm folded into the GEMM (rowscale / colvec), ragged M, residual ring
             ('9', '0'),                          # ... through the GEGLU epilogue (128-row)
-            ('10', '0'),                         # ... alone
-            ('12', '0'), ('13', '0'), ('14', '0'),   # the remaining kernel kinds: plain / LayerNorm 128-row, LayerNorm GEGLU 256-row
             ('15', '0'),                         # 3x3 convolution, two sources, row-vector ring
-            ('16', '0'),                         # stride 2, 128-row tiles
             ('19', '0'),                         # 48 rows per vector: 32-row blocks that meet two row vectors
-            ('20', '0'), ('21', '0')]            # convolution without an addend, both tile heights
+            ('21', '0')]                         # convolution without an addend, 128-row tiles
+    # (`make -C tools/cpu_check run` walks every case: the remaining kernel kinds, stride 2, nearest-2x, K tails)
     for case, scheds in runs:
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900)
         print(r.stdout)
