@@ -96,3 +96,21 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
             r = subprocess.run([exe, case], capture_output=True, text=True, timeout=600, env=dict(env, VSX_TUNE_TILE=tile))
             print('VSX_TUNE_TILE=' + tile, r.stdout)
             assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_normalisation_kernels_run_on_the_cpu(tmp_path):
+    """csrc/norm.hip from its real source on the host: GroupNorm statistics / finalize / apply (4-D and 5-D scopes, the two-source
+    concat with groups that straddle the sources, SiLU, C = 2560), LayerNorm (three vector widths, temporal positional encoding),
+    the row statistics of the LayerNorm fold, plain and causal row softmax — against double precision
+    (tools/cpu_check/check_norm.cpp)."""
+    cxx = CXX if os.path.isfile(CXX) else shutil.which('clang++')
+    src = os.path.join(ROOT, 'tools', 'cpu_check')
+    exe = str(tmp_path / 'check_norm')
+    cmd = [cxx, '-std=c++20', '-O1', '-pthread', '-I', src, '-I', os.path.join(ROOT, 'include'), '-I',
+           os.path.join(ROOT, 'videoswap_amd', 'csrc'), '-Wno-unused-function', '-Wno-unused-value', '-o', exe,
+           os.path.join(src, 'check_norm.cpp')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    print(r.stdout)
+    assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
