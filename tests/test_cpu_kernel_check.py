@@ -114,3 +114,29 @@ def test_normalisation_kernels_run_on_the_cpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     print(r.stdout)
     assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_attention_kernels_run_on_the_cpu(tmp_path):
+    """csrc/attention.hip on the host: the flash kernel (d = 40 / 64 / 80 / 160, ragged query and key tiles, K / V shared by two
+    query batches), the temporal kernel with (site, head) problems packed into 32x32 MFMA tiles (16 and 24 frames, 4 frames with 8
+    heads per tile), its long-clip form (16 x 64, 8 x 40 frames) and the VALU fallback, against a double-precision
+    softmax(Q K^T) V (tools/cpu_check/check_attention.cpp; two textual rewrites of the source, attention_cpu.sed)."""
+    cxx = CXX if os.path.isfile(CXX) else shutil.which('clang++')
+    src = os.path.join(ROOT, 'tools', 'cpu_check')
+    gen = tmp_path / 'gen'
+    gen.mkdir()
+    with open(gen / 'attention_cpu.hip', 'w') as f:
+        r = subprocess.run(['sed', '-f', os.path.join(src, 'attention_cpu.sed'),
+                            os.path.join(ROOT, 'videoswap_amd', 'csrc', 'attention.hip')], stdout=f, text=True)
+    assert r.returncode == 0
+    text = open(gen / 'attention_cpu.hip').read()
+    assert 'cpuhip_dyn_lds' in text and text.count('wave_bar->arrive_and_wait(); const h8 vf') == 2      # both rewrites applied
+    exe = str(tmp_path / 'check_attention')
+    cmd = [cxx, '-std=c++20', '-O1', '-pthread', '-I', src, '-I', str(gen), '-I', os.path.join(ROOT, 'include'), '-I',
+           os.path.join(ROOT, 'videoswap_amd', 'csrc'), '-Wno-unused-function', '-Wno-unused-value', '-Wno-division-by-zero',
+           '-o', exe, os.path.join(src, 'check_attention.cpp')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    print(r.stdout)
+    assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
