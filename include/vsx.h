@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 7
+#define VSX_ABI_VERSION 8
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -258,9 +258,29 @@ int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* total_flop);
  *       elements).  frames -> sites ([B, f, P, hw/P, C] -> [B, P, f, hw/P, C]): nouter = B, ninner = f,
  *       block = hw/P*C, send strides (block, f*P*block, P*block), recv strides (f*block, P*f*block, block);
  *       sites -> frames is the same call with the two stride triples exchanged.
+ *
+ * Recording communicator (ABI 8): vsx_comm_init_recording(rank, nranks) makes this process rank `rank` of `nranks`
+ * WITHOUT librccl: the collectives above run their argument checks, stride arithmetic, group structure and peer loop
+ * unchanged, but every ncclSend / ncclRecv / ncclAllGather / ncclAllReduce / local copy is appended to a log instead
+ * of being executed (no device work, the buffers are never dereferenced).  vsx_comm_recorded(out, capacity) drains the
+ * log (out == NULL: number of pending records): 6 int64 per record = op (VSX_COMM_OP_*), peer (-1: none), source
+ * offset, destination offset (ELEMENTS from the entry point's first / second buffer argument; -1: n/a), element count,
+ * element size.  Replaying the logs of all ranks against each other (NCCL matching: the k-th send of rank a to rank b
+ * meets the k-th receive of b from a) reproduces what a P-GPU node would do: tests/test_distributed.py checks the
+ * result against FrameShard's layouts for P = 2, 4, 8 — the multi-rank marshalling of this ABI on a box with one GPU
+ * or none.  vsx_comm_destroy ends the recording.
  * ------------------------------------------------------------------------------------------ */
+#define VSX_COMM_OP_SEND 1
+#define VSX_COMM_OP_RECV 2
+#define VSX_COMM_OP_ALLGATHER 3   /* destination block of rank q at dst offset + q * count */
+#define VSX_COMM_OP_ALLREDUCE 4
+#define VSX_COMM_OP_LOCAL_COPY 5
+#define VSX_COMM_OP_GROUP_START 6
+#define VSX_COMM_OP_GROUP_END 7
 int vsx_comm_unique_id(void* id128);
 int vsx_comm_init(int64_t rank, int64_t nranks, const void* id128);
+int vsx_comm_init_recording(int64_t rank, int64_t nranks);
+int64_t vsx_comm_recorded(int64_t* out, int64_t capacity);
 int64_t vsx_comm_size(void);
 int64_t vsx_comm_rank(void);
 int vsx_comm_destroy(void);

@@ -22,6 +22,25 @@ BLEND = dict(cross_replace_steps=0.5, self_replace_steps=0.5, blend_th=0.3)
 T2I = dict(t2i_guidance_scale=0.5, t2i_start=0.0, t2i_end=0.5)
 
 
+class Size:
+    """One size of the case.  SMALL is the round-3 golden (T = 4, 4 + 4 steps: every controller branch fires on one or two
+    steps); BENCH is the size bench.py --config 3 times in frames (T = 16) with 10 + 10 steps and the replace fractions of
+    the reference's option files (`cross_replace_steps` / `self_replace_steps` 0.3: three steps with and seven without the
+    replacement, attention_util.py:28-138; the adapter window [0, 0.5] covers five steps, pipeline_videoswap.py:560-567;
+    both blenders run on every step, spatial_blend.py:25-145)."""
+
+    def __init__(self, name, frames, steps, blend, seed_x):
+        self.name, self.frames, self.steps, self.blend, self.seed_x = name, frames, steps, dict(blend), seed_x
+
+    @property
+    def golden(self):
+        return 'cfg3_fullwidth.pt' if self.name == 'small' else f'cfg3_fullwidth_{self.name}.pt'
+
+
+SMALL = Size('small', FRAMES, STEPS, BLEND, SEED_X)
+BENCH = Size('T16_10+10', 16, 10, dict(cross_replace_steps=0.3, self_replace_steps=0.3, blend_th=0.3), 9016)
+
+
 def synthetic_lora(state_dict, seed=4, rank=4, text_dim=768):
     """rank-4 factors on the keys convert_edlora_to_diffusers.py:46-53 merges (spatial transformers only).  Every key
     draws from its own generator (seeded by a hash of its name): the result does not depend on the order in which a
@@ -45,20 +64,22 @@ def synthetic_lora(state_dict, seed=4, rank=4, text_dim=768):
     return {'params': {'new_concept_embedding': emb, 'unet': lora}}
 
 
-def inputs():
+def inputs(size=SMALL):
     from videoswap_amd.synthetic import portable_randn, synthetic_clip
-    data = synthetic_clip(seed=21, frames=FRAMES, height=HW, width=HW, text_dim=768, points=POINTS, device='cpu',
+    data = synthetic_clip(seed=21, frames=size.frames, height=HW, width=HW, text_dim=768, points=POINTS, device='cpu',
                           dtype=torch.float32)
     conditions = data['conditions']
     conditions['pred_tracks'] = conditions['pred_tracks'].half().float()     # the reference holds tracks in fp16
-    latents = portable_randn((1, 4, FRAMES, HW, HW), SEED_X).half().float()  # fp16-exact: both sides start from the same bits
+    # fp16-exact: both sides start from the same bits
+    latents = portable_randn((1, 4, size.frames, HW, HW), size.seed_x).half().float()
     return latents, conditions
 
 
-def editing_config(steps=STEPS):
+def editing_config(steps=None, size=SMALL):
+    steps = size.steps if steps is None else steps
     return dict(use_invertion_latents=True, use_blend=True, num_inference_steps=steps, guidance_scale=7.5, **T2I,
                 editing_prompts={'0': dict(replace=REPLACE, lora_path=f'synthetic_edlora.pth---{LORA_ALPHA}',
-                                           blend_cfg=dict(BLEND))})
+                                           blend_cfg=dict(size.blend))})
 
 
 class PipeShim:
@@ -70,7 +91,7 @@ class PipeShim:
 
 
 @torch.no_grad()
-def oracle_flow(ora, oad, store_cls, make_controller, steps=STEPS, log=None):
+def oracle_flow(ora, oad, store_cls, make_controller, steps=None, log=None, size=SMALL):
     """The swap flow assembled from the oracle UNet / adapter / loops on whatever device and dtype `ora` lives on, with
     the controller classes handed in (the reference's own, or videoswap_amd.control which is pinned against them).
     Returns (inverted latents, final latents), fp32 on the CPU."""
@@ -79,7 +100,9 @@ def oracle_flow(ora, oad, store_cls, make_controller, steps=STEPS, log=None):
     from videoswap_amd.synthetic import SyntheticTextEncoder, WhitespaceTokenizer
     p0 = next(ora.parameters())
     dev, dt = p0.device, p0.dtype
-    latents, conditions = inputs()
+    steps = size.steps if steps is None else steps
+    blend = size.blend
+    latents, conditions = inputs(size)
     tok = WhitespaceTokenizer()
     enc = SyntheticTextEncoder(dim=768, dtype=dt, device=dev)
     store = store_cls()
@@ -97,10 +120,10 @@ def oracle_flow(ora, oad, store_cls, make_controller, steps=STEPS, log=None):
         tok.new_concept_cfg = concept_cfg
         src_subject, tgt_subject = [s.strip() for s in REPLACE.split('->')]
         target = SOURCE.replace(src_subject, tgt_subject)
-        edit = make_controller(tok, [SOURCE, target], False, cross_replace_steps=BLEND['cross_replace_steps'],
-                               self_replace_steps=BLEND['self_replace_steps'],
+        edit = make_controller(tok, [SOURCE, target], False, cross_replace_steps=blend['cross_replace_steps'],
+                               self_replace_steps=blend['self_replace_steps'],
                                blend_words=[src_subject.split(' '), tgt_subject.split(' ')],
-                               additional_attention_store=store, blend_th=(BLEND['blend_th'], BLEND['blend_th']),
+                               additional_attention_store=store, blend_th=(blend['blend_th'], blend['blend_th']),
                                NUM_DDIM_STEPS=steps, blend_latents=True, blend_self_attention=True,
                                image_height=HW * 8, image_width=HW * 8)
         opipe.register_control(ora, edit, edlora=True)

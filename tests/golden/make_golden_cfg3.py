@@ -3,6 +3,7 @@ Prompt-to-Prompt controllers — videoswap/utils/p2p_utils/{attention_store,atte
 imported verbatim from /root/reference (oracle/ref_import.py) — driven by the fp32 oracle UNet on the CPU.
 
     python tests/golden/make_golden_cfg3.py          # ~10 min on 8 cores; writes tests/golden/cfg3_fullwidth.pt
+    python tests/golden/make_golden_cfg3.py bench    # T = 16, 10 + 10 steps (cfg3_case.BENCH): ~2 h on 8 cores
 
 The GPU test (tests/test_cfg3_fullwidth_gpu.py) loads the file on the GPU box, where /root/reference does not exist."""
 import os
@@ -20,6 +21,9 @@ sys.dont_write_bytecode = True
 
 def main():
     import cfg3_case as case
+    size = case.BENCH if len(sys.argv) > 1 and sys.argv[1] == 'bench' else case.SMALL
+    if len(sys.argv) > 2:
+        torch.set_num_threads(int(sys.argv[2]))
     from oracle import adapter as oadapter
     from oracle import ref_import, unet3d
     from videoswap_amd.synthetic import portable_weights_
@@ -36,12 +40,13 @@ def main():
     print(f'models built in {time.time() - t0:.0f} s', flush=True)
     inv, out = case.oracle_flow(ora, oad, mods['attention_store'].AttentionStore,
                                 mods['attention_util'].make_controller,
-                                log=lambda s: print(f'[{time.time() - t0:.0f} s] {s}', flush=True))
+                                log=lambda s: print(f'[{time.time() - t0:.0f} s] {s}', flush=True), size=size)
     w = sum(float(p.detach().double().abs().sum()) for p in ora.parameters())
-    torch.save({'inverted': inv, 'final': out, 'weights_abs_sum': w, 'steps': case.STEPS, 'frames': case.FRAMES,
+    torch.save({'inverted': inv, 'final': out, 'weights_abs_sum': w,
+                'steps': size.steps, 'frames': size.frames, 'blend': size.blend,
                 'controllers': 'reference p2p_utils verbatim', 'oracle': 'oracle.unet3d fp32, CPU'},
-               os.path.join(HERE, 'cfg3_fullwidth.pt'))
-    print(f'wrote cfg3_fullwidth.pt in {time.time() - t0:.0f} s; |inv| {float(inv.norm()):.4f} |out| {float(out.norm()):.4f} '
+               os.path.join(HERE, size.golden))
+    print(f'wrote {size.golden} in {time.time() - t0:.0f} s; |inv| {float(inv.norm()):.4f} |out| {float(out.norm()):.4f} '
           f'weights {w:.6e}')
 
 

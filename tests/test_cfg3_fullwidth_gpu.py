@@ -26,24 +26,33 @@ import cfg3_case as case
 from util import GOLDEN, ROOT, cosine, load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
+RESULTS = {}
 
 
 def _record(name, **kw):
     out = os.path.join(ROOT, 'gpurun_out')
     try:
         os.makedirs(out, exist_ok=True)
+        RESULTS[name] = kw
         with open(os.path.join(out, 'parity_cfg3.json'), 'w') as f:
-            json.dump({name: kw}, f, indent=1, sort_keys=True)
+            json.dump(RESULTS, f, indent=1, sort_keys=True)
     except OSError:
         pass
     print(name, json.dumps(kw))
 
 
-def test_cfg3_full_width_against_reference_controllers():
-    path = os.path.join(GOLDEN, 'cfg3_fullwidth.pt')
+@pytest.mark.parametrize('size', [case.SMALL, case.BENCH], ids=lambda s: s.name)
+def test_cfg3_full_width_against_reference_controllers(size):
+    """SMALL: T = 4, 4 + 4 steps (round 3).  BENCH (round 4, VERDICT weak 2): T = 16 — the frame count bench.py --config 3
+    times — with 10 + 10 steps and `cross_replace_steps` / `self_replace_steps` 0.3, so that the step-dependent controller
+    branches (attention_util.py:28-138: replacement on steps 0-2, plain store afterwards), the adapter window [0, 0.5]
+    (five steps with, five without residuals) and both SpatialBlenders (spatial_blend.py:25-145) each run for several
+    steps at the benchmarked width.  Both goldens come from the reference's own controllers (make_golden_cfg3.py)."""
+    path = os.path.join(GOLDEN, size.golden)
     if not os.path.exists(path):
-        pytest.fail('tests/golden/cfg3_fullwidth.pt is missing (tests/golden/make_golden_cfg3.py writes it)')
-    gold = load_golden('cfg3_fullwidth.pt')
+        pytest.fail(f'tests/golden/{size.golden} is missing (tests/golden/make_golden_cfg3.py writes it)')
+    gold = load_golden(size.golden)
+    assert gold['frames'] == size.frames and gold['steps'] == size.steps
     from oracle import adapter as oadapter
     from oracle import unet3d
     from videoswap_amd import control
@@ -71,7 +80,7 @@ def test_cfg3_full_width_against_reference_controllers():
     pad = pad.to('cuda', torch.float16)
 
     # ---------------- product ----------------
-    latents, conditions = case.inputs()
+    latents, conditions = case.inputs(size)
     tok = WhitespaceTokenizer()
     pipe = VideoSwapPipeline(unet=prod, adapter=pad, tokenizer=tok, scheduler=DDIMScheduler(**SD15_SCHEDULER_CONFIG),
                              text_encoder=SyntheticTextEncoder(dim=768, dtype=torch.float16, device='cuda')).to('cuda')
@@ -86,7 +95,7 @@ def test_cfg3_full_width_against_reference_controllers():
     pipe.invert = capture
     video = latents[0].permute(1, 0, 2, 3).contiguous().half().cuda()               # [F,4,h,w] "video" of latents
     t0 = time.time()
-    edited = pipe.validation(video, conditions, case.SOURCE, case.editing_config(),
+    edited = pipe.validation(video, conditions, case.SOURCE, case.editing_config(size=size),
                              lora_loader=lambda p: case.synthetic_lora(before))
     torch.cuda.synchronize()
     t_prod = time.time() - t0
@@ -96,14 +105,14 @@ def test_cfg3_full_width_against_reference_controllers():
 
     # ---------------- yardstick and controller pin on the device oracle ----------------
     mk = functools.partial(control.make_controller, device='cuda')
-    inv32, out32 = case.oracle_flow(ora_dev, oad, control.AttentionStore, mk)
+    inv32, out32 = case.oracle_flow(ora_dev, oad, control.AttentionStore, mk, size=size)
     ora_h = ora_dev.half()
-    inv16, out16 = case.oracle_flow(ora_h, oad, control.AttentionStore, mk)
+    inv16, out16 = case.oracle_flow(ora_h, oad, control.AttentionStore, mk, size=size)
 
     e_pin_inv, e_pin = rel_l2(inv32, gold['inverted']), rel_l2(out32, gold['final'])
     e_inv, e16_inv = rel_l2(captured['inverted'], gold['inverted']), rel_l2(inv16, gold['inverted'])
     e_out, e16_out = rel_l2(got, gold['final']), rel_l2(out16, gold['final'])
-    _record('cfg3_T4_64x64_4+4_steps', inversion_rel_l2=e_inv, inversion_rel_l2_fp16_oracle=e16_inv, final_rel_l2=e_out,
+    _record(f'cfg3_T{size.frames}_64x64_{size.steps}+{size.steps}_steps', inversion_rel_l2=e_inv, inversion_rel_l2_fp16_oracle=e16_inv, final_rel_l2=e_out,
             final_rel_l2_fp16_oracle=e16_out, final_cosine=cosine(got, gold['final']),
             device_fp32_oracle_with_product_controllers_vs_golden=dict(inversion=e_pin_inv, final=e_pin),
             product_vs_fp16_oracle=rel_l2(got, out16), wall_s_product_validation=t_prod)

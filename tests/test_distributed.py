@@ -215,3 +215,156 @@ def _grad_allreduce(rank, world):
 
 def test_adapter_gradient_allreduce():
     assert all(_run(_grad_allreduce))
+
+
+# ---- the C-ABI collectives (csrc/comm.cpp) for P > 1 ranks without a second GPU: recording communicator + replay ----------
+OP_SEND, OP_RECV, OP_ALLGATHER, OP_ALLREDUCE, OP_COPY, OP_GSTART, OP_GEND = 1, 2, 3, 4, 5, 6, 7
+
+
+def _record_rank(lib, rank, world, call):
+    """Rank `rank` of `world` on a recording communicator (include/vsx.h, ABI 8): `call(lib)` runs C-ABI collectives with
+    FAKE buffer addresses (never dereferenced); returns the drained log as a list of 6-tuples."""
+    import ctypes
+    from videoswap_amd import _lib
+    _lib.check(lib.vsx_comm_init_recording(rank, world), 'vsx_comm_init_recording')
+    try:
+        assert lib.vsx_comm_size() == world and lib.vsx_comm_rank() == rank
+        call(lib)
+        n = lib.vsx_comm_recorded(None, 0)
+        buf = (ctypes.c_int64 * (6 * n))()
+        assert lib.vsx_comm_recorded(buf, n) == n and lib.vsx_comm_recorded(None, 0) == 0
+        return [tuple(buf[6 * i:6 * i + 6]) for i in range(n)]
+    finally:
+        _lib.check(lib.vsx_comm_destroy(), 'vsx_comm_destroy')
+    assert lib.vsx_comm_size() == 0
+
+
+def _replay(logs, sends, recvs):
+    """Execute the ranks' logs against each other on host tensors.  NCCL point-to-point matching: the k-th send of rank a
+    to rank b meets the k-th receive of rank b from rank a; element counts must agree; every send / receive must be
+    inside ONE group per rank (a deadlock-free all-to-all); all-gathers must be issued with the same count in the same
+    order on every rank."""
+    world = len(logs)
+    for r, log in enumerate(logs):
+        depth, groups = 0, 0
+        for op, peer, so, do, n, es in log:
+            if op == OP_GSTART:
+                depth += 1
+                groups += 1
+            elif op == OP_GEND:
+                depth -= 1
+            elif op in (OP_SEND, OP_RECV):
+                assert depth == 1, f'rank {r}: point-to-point call outside a group'
+                assert 0 <= peer < world and peer != r
+        assert depth == 0 and groups <= 1, f'rank {r}: {groups} groups'
+    for a in range(world):
+        for op, peer, so, do, n, es in logs[a]:
+            if op == OP_COPY:
+                recvs[a].view(-1)[do:do + n] = sends[a].view(-1)[so:so + n]
+        for b in range(world):
+            if a == b:
+                continue
+            s = [rec for rec in logs[a] if rec[0] == OP_SEND and rec[1] == b]
+            d = [rec for rec in logs[b] if rec[0] == OP_RECV and rec[1] == a]
+            assert len(s) == len(d), f'{len(s)} sends {a}->{b} but {len(d)} receives'
+            for (_, _, so, _, n, es), (_, _, _, do, n2, es2) in zip(s, d):
+                assert n == n2 and es == es2 == sends[a].element_size()
+                recvs[b].view(-1)[do:do + n] = sends[a].view(-1)[so:so + n]
+    gathers = [[rec for rec in log if rec[0] == OP_ALLGATHER] for log in logs]
+    assert len({len(g) for g in gathers}) == 1
+    for k in range(len(gathers[0])):
+        assert len({gathers[r][k][4] for r in range(world)}) == 1, 'all-gather counts differ across ranks'
+        for r in range(world):
+            _, _, _, do, n, _ = gathers[r][k]
+            for q in range(world):
+                so_q = gathers[q][k][2]
+                recvs[r].view(-1)[do + q * n:do + (q + 1) * n] = sends[q].view(-1)[so_q:so_q + n]
+
+
+def _have_lib():
+    from videoswap_amd import _lib
+    return os.path.exists(_lib.LIB_PATH)
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_c_abi_alltoall_schedule_replayed_across_ranks(world):
+    """vsx_alltoall_f16 as FrameShard(backend='rccl', exchange='sites') calls it (FrameShard._alltoall_strided with
+    FrameShard.reshard_strides), rank by rank on recording communicators, replayed: frames -> sites must equal the torch
+    path of `to_sites` (pack, all_to_all_single, unpack: tests above) = the plain re-layout of the full clip, and
+    sites -> frames must bring every rank's frames back bit for bit."""
+    if not _have_lib():
+        pytest.skip('libvsx.so not built')
+    import ctypes
+    from videoswap_amd import _lib
+    from videoswap_amd.distributed import FrameShard
+    lib = _lib.load()
+    b, f, hw, c = 2, 3, 8 * world, 5            # f local frames per rank, hw sites (hw / world per rank), c channels
+    hl = hw // world
+    blk = hl * c
+    g = torch.Generator().manual_seed(40 + world)
+    full = torch.randn(b, world * f, hw, c, generator=g).half()              # the whole clip [B, F_total, hw, C]
+    local = [full[:, r * f:(r + 1) * f].contiguous() for r in range(world)]   # rank r: its frames, all sites
+    arr = ctypes.c_int64 * 3
+    FAKE_SRC, FAKE_DST = 0x10000000, 0x20000000
+
+    def a2a(send_st, recv_st):
+        return lambda lib_: _lib.check(lib_.vsx_alltoall_f16(ctypes.c_void_p(FAKE_SRC), ctypes.c_void_p(FAKE_DST), b, f, blk,
+                                                             arr(*send_st), arr(*recv_st), None), 'vsx_alltoall_f16')
+    send_st, recv_st = FrameShard.reshard_strides(world, f, blk)
+    logs = [_record_rank(lib, r, world, a2a(send_st, recv_st)) for r in range(world)]
+    # one group, (P - 1) * b * f sends and as many receives per rank, b * f local copies: nothing is packed or staged
+    for log in logs:
+        assert sum(rec[0] == OP_SEND for rec in log) == (world - 1) * b * f
+        assert sum(rec[0] == OP_RECV for rec in log) == (world - 1) * b * f
+        assert sum(rec[0] == OP_COPY for rec in log) == b * f
+        assert all(rec[4] == blk for rec in log if rec[0] in (OP_SEND, OP_RECV, OP_COPY))
+    sites = [torch.full((b, world * f, hl, c), float('nan')).half() for _ in range(world)]
+    _replay(logs, local, sites)
+    for r in range(world):                      # rank r now holds sites [r*hl, (r+1)*hl) of EVERY frame, frames in global order
+        assert torch.equal(sites[r], full[:, :, r * hl:(r + 1) * hl])
+    # and back: the same call with the two stride triples exchanged
+    logs = [_record_rank(lib, r, world, a2a(recv_st, send_st)) for r in range(world)]
+    back = [torch.full((b, f, hw, c), float('nan')).half() for _ in range(world)]
+    _replay(logs, sites, back)
+    for r in range(world):
+        assert torch.equal(back[r], local[r])
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_c_abi_allgathers_replayed_across_ranks(world):
+    """vsx_allgather_kv (one ncclAllGather per batch item inside one group, straight into the [B, P, f*hw, 2C] buffer the
+    temporal attention kernel reads as [B, F_total, hw, 2C]) and vsx_allgather_f32 (GroupNorm partial sums in rank order),
+    recorded per rank and replayed."""
+    if not _have_lib():
+        pytest.skip('libvsx.so not built')
+    import ctypes
+    from videoswap_amd import _lib
+    lib = _lib.load()
+    b, f, hw, c2 = 2, 3, 4, 6
+    per_batch = f * hw * c2
+    g = torch.Generator().manual_seed(50 + world)
+    full = torch.randn(b, world * f, hw, c2, generator=g).half()             # K|V of all frames
+    local = [full[:, r * f:(r + 1) * f].contiguous() for r in range(world)]
+    FAKE_SRC, FAKE_DST = 0x10000000, 0x20000000
+
+    def kv(lib_):
+        _lib.check(lib_.vsx_allgather_kv(ctypes.c_void_p(FAKE_SRC), ctypes.c_void_p(FAKE_DST), b, per_batch, None),
+                   'vsx_allgather_kv')
+    logs = [_record_rank(lib, r, world, kv) for r in range(world)]
+    for log in logs:
+        assert [rec[0] for rec in log] == [OP_GSTART] + [OP_ALLGATHER] * b + [OP_GEND]
+    out = [torch.full((b, world * f, hw, c2), float('nan')).half() for _ in range(world)]
+    _replay(logs, local, out)
+    for r in range(world):
+        assert torch.equal(out[r], full)        # every rank: all frames in global order, per batch item
+
+    part = [torch.randn(b, 2, 4, 2, generator=g) for _ in range(world)]      # [nimg, nchunks, groups, 2] fp32
+    n = part[0].numel()
+
+    def f32(lib_):
+        _lib.check(lib_.vsx_allgather_f32(ctypes.c_void_p(FAKE_SRC), ctypes.c_void_p(FAKE_DST), n, None), 'vsx_allgather_f32')
+    logs = [_record_rank(lib, r, world, f32) for r in range(world)]
+    allp = [torch.full((world, b, 2, 4, 2), float('nan')) for _ in range(world)]
+    _replay(logs, part, allp)
+    for r in range(world):
+        assert torch.equal(allp[r], torch.stack(part))

@@ -190,6 +190,49 @@ def test_forward_edlora_text_and_adapter_residuals(models):
                 m.set_processor(AttnProcessor2_0())
 
 
+def test_forward_outlier_stress(models):
+    """(4b) activation-outlier stress of the fp16 epilogues: the seeded synthetic weights give
+    well-behaved activations, real checkpoints do not.  A handful of GroupNorm / LayerNorm gains and one attention
+    `to_out` / one feed-forward output weight are scaled x30 (in the product AND both oracles, restored afterwards), so
+    that GEMM epilogues, the folded-LayerNorm identity, GEGLU and the fp16 residual stream see values two orders of
+    magnitude above the rest — the folded LayerNorm (rstd * acc - rstd * mean * c1) is the place where a cancellation
+    would show.  Same <= 2x fp16-storage-oracle rule; nothing may overflow to inf."""
+    cfg, ora, ora_dev, ora_h, prod = models
+    names = ['down_blocks.0.resnets.0.norm2.weight', 'down_blocks.1.attentions.0.norm.weight',
+             'down_blocks.0.attentions.1.transformer_blocks.0.norm1.weight',
+             'down_blocks.0.attentions.1.transformer_blocks.0.norm3.weight',
+             'up_blocks.3.attentions.2.transformer_blocks.0.norm2.weight',
+             'down_blocks.0.motion_modules.0.temporal_transformer.transformer_blocks.0.norms.0.weight',
+             'up_blocks.3.motion_modules.1.temporal_transformer.transformer_blocks.0.ff_norm.weight',
+             'up_blocks.2.attentions.0.transformer_blocks.0.attn1.to_out.0.weight',
+             'mid_block.attentions.0.transformer_blocks.0.ff.net.2.weight',
+             'up_blocks.3.resnets.1.norm1.weight']
+    mods = (prod, ora_dev, ora_h)
+    saved = []
+    with torch.no_grad():
+        for m in mods:
+            sd = dict(m.named_parameters())
+            for n in names:
+                assert n in sd, n
+                saved.append((sd[n], sd[n].detach().clone()))
+                sd[n].mul_(30.0)
+            if hasattr(m, 'bump_weights_epoch'):
+                m.bump_weights_epoch()
+    try:
+        x, txt = _inputs(2, 4, 64, 64, seed=131)
+        ref = _fwd(ora_dev, x, 621, txt)
+        out = _fwd(prod, x, 621, txt)
+        _check('unet_B2_T4_64x64_outlier_stress', out, ref, _fwd(ora_h, x, 621, txt),
+               extra=dict(out_absmax=float(out.abs().max()), ref_absmax=float(ref.abs().max())))
+    finally:
+        with torch.no_grad():
+            for p_, v in saved:
+                p_.copy_(v)
+            for m in mods:
+                if hasattr(m, 'bump_weights_epoch'):
+                    m.bump_weights_epoch()
+
+
 @torch.no_grad()
 def _oracle_loops(model, x, txt, neg, steps, guidance=7.5):
     from oracle import pipeline as opipe
@@ -213,17 +256,13 @@ def _product_loops(prod, x, txt, neg, steps, guidance=7.5):
     return inv.float().cpu(), out.float().cpu()
 
 
-HEAVY = pytest.mark.skipif(os.environ.get('VSX_HEAVY_TESTS') != '1',
-                           reason='several minutes of oracle time: run with VSX_HEAVY_TESTS=1 (last recorded result: '
-                                  'profiles/r02_parity_fullwidth_run1.json)')
-
-
-@pytest.mark.parametrize('steps', [5, 20, pytest.param(50, marks=HEAVY)])
+@pytest.mark.parametrize('steps', [5, 50])
 def test_sequential_steps_full_width(models, steps):
     """(5) `steps` inversion steps (B = 1) + `steps` CFG-7.5 sampling steps (B = 2) at T = 16, 64x64: config 2 of
-    BASELINE.json for steps = 50 (the run bench.py times); 20 + 20 steps run in every `-m gpu` pass (under a minute with
-    the device-placed oracles), 50 + 50 behind VSX_HEAVY_TESTS.  The final latents obey the same <= 2x rule against the
-    fp16-storage oracle pushed through the same loops (fp16 error compounds over sequential UNet calls)."""
+    BASELINE.json for steps = 50 — the very loop bench.py times (pipeline_videoswap.py:677-710, :555-601) — runs in
+    every `-m gpu` pass since round 4 (about 45 s with the device-placed oracles; the 20 + 20 case it replaces cost 19 s).
+    The final latents obey the same <= 2x rule against the fp16-storage oracle pushed through the same loops (fp16
+    error compounds over sequential UNet calls)."""
     cfg, ora, ora_dev, ora_h, prod = models
     x, txt = _inputs(1, 16, 64, 64, seed=107 + steps)
     neg = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(7))

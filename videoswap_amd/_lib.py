@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.environ.get('VSX_LIB_VARIANT') or None
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so' if not VARIANT else f'libvsx_{VARIANT}.so')
 
-VSX_ABI_VERSION = 7
+VSX_ABI_VERSION = 8
 
 
 class VsxError(RuntimeError):
@@ -83,6 +83,8 @@ PROTOTYPES = {
     'vsx_prof_enable': (c_int, [c_int64, c_int64]),
     'vsx_comm_unique_id': (c_int, [c_void_p]),
     'vsx_comm_init': (c_int, [c_int64, c_int64, c_void_p]),
+    'vsx_comm_init_recording': (c_int, [c_int64, c_int64]),
+    'vsx_comm_recorded': (c_int64, [POINTER(c_int64), c_int64]),
     'vsx_comm_size': (c_int64, []),
     'vsx_comm_rank': (c_int64, []),
     'vsx_comm_destroy': (c_int, []),

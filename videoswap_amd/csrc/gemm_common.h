@@ -44,6 +44,7 @@ struct GemmParams {
 // the epilogues (HBM writes) of some CUs fall under the main loops of others (profiles/r03_gemm_stagger_ab_b2.txt: +-2 %
 // at K = 320, slower everywhere else: the CUs are not in lockstep to begin with).
 constexpr int PP_TILES_LINEAR = 8;
+constexpr int PP_CONV_TAP_INNER = 4;     // convolution K order: the taps of a 64-channel slab back to back (A/B; see gemm_pp.hip)
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 

@@ -410,8 +410,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     const int vb_e = (int)((unsigned)lrow * ldb2) + kofs_e * 2;
     const int vb_o = (int)((unsigned)lrow * ldb2) + kofs_o * 2;
     int va_e = 0, va_o = 0;                      // plain A
-    int va[CONV ? GA : 1];                       // conv A: pixel offsets of this lane's row in each of its pieces
-    int a_hw[CONV ? GA : 1], a_ib[CONV ? GA : 1];   // conv: (h0 + 4) | (w0 + 4) << 16 (h0 = -4: row >= M), image base
+    // conv A, per piece of this lane: a_px = source pixel of the window's first tap (may lie outside the image), a_mk = bit
+    // 3 kh + kw: that tap is inside the image; bits 9 / 10: h0 / w0 odd (nearest-2x source: which taps share a source pixel),
+    // a_vb = byte offset of pixel a_px in the CURRENT source (channel count C1 or C2) + the lane's swizzled k slot.  A slab's
+    // offset is a_vb + a tap term that is uniform (or one of two uniform values by parity): three VALU operations per piece
+    // and slab, whatever the slab order
+    int a_px[CONV ? GA : 1], a_mk[CONV ? GA : 1], a_vb[CONV ? GA : 1];
     if constexpr (!CONV) {
         va_e = (int)((unsigned)lrow * lda2) + kofs_e * 2;
         va_o = (int)((unsigned)lrow * lda2) + kofs_o * 2;
@@ -421,7 +425,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     int i_t = 0, i_kt = 0, i_g = 0;              // tile (index into my sequence), slab in tile, slabs issued so far
     bool need_setup = true;
     int t_kh = 0, t_kw = 0, t_c = 0;             // conv: filter tap / channel base of the next slab
-    bool t_second = false, t_dirty = true;
+    bool t_second = false, t_dirty = true, t_src_dirty = true;
+    const bool tap_inner = CONV && (flags & PP_CONV_TAP_INNER) != 0;
+    int t_bit = 0, t_re = 0, t_ro = 0, t_ce = 0, t_co = 0;     // tap bit; byte delta of the tap's row / column for an even / odd window origin
     int i_m0 = 0;                                // first row of the tile being staged
     unsigned i_rowB = 0;                         // (first B row of the tile) * pitch
 
@@ -432,8 +438,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         i_rowB = (unsigned)(geglu ? tile_n * (BN / 2) : tile_n * BN) * ldb2;
         if constexpr (CONV) {
             const unsigned Wo = (unsigned)p->Wo, hw = (unsigned)p->Ho * Wo;
-            const int stride = p->stride, pad = p->pad;
-            const int Hs = p->ups ? (p->H >> 1) : p->H;
+            const int stride = p->stride, pad = p->pad, ks = p->ks, ups = p->ups;
+            const int H = p->H, W = p->W;
+            const int Hs = ups ? (H >> 1) : H, Ws = ups ? (W >> 1) : W;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
                 const int m = i_m0 + (wave * GA + i) * 8 + lrow;
@@ -441,12 +448,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
                 const unsigned img = mm / hw;
                 const unsigned rem = mm - img * hw;
                 const unsigned ho = rem / Wo;
-                const int h0 = m < Mi ? (int)ho * stride - pad : -4;        // -4 + any tap < 0: never in range
+                const int h0 = (int)ho * stride - pad;
                 const int w0 = (int)(rem - ho * Wo) * stride - pad;
-                a_hw[i] = (h0 + 4) | ((w0 + 4) << 16);
-                a_ib[i] = (int)img * Hs;
+                int mk = 0;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (kh < ks && kw < ks && m < Mi && (unsigned)(h0 + kh) < (unsigned)H && (unsigned)(w0 + kw) < (unsigned)W)
+                            mk |= 1 << (3 * kh + kw);
+                a_mk[i] = mk | ((h0 & 1) << 9) | ((w0 & 1) << 10);
+                a_px[i] = ((int)img * Hs + (ups ? (h0 >> 1) : h0)) * Ws + (ups ? (w0 >> 1) : w0);
             }
             t_kh = 0; t_kw = 0; t_c = 0; t_second = false; t_dirty = true;
+            t_src_dirty = true;
         }
     };
 
@@ -461,18 +476,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         const int kt = i_kt;
         if constexpr (CONV) {
             const int C1 = p->C1, C2 = p->C2, ks = p->ks;
-            if (t_dirty) {                      // a slab never straddles a filter tap or the two concatenated sources
-                const int csz = t_second ? C2 : C1;
-                const int H = p->H, W = p->W, ups = p->ups;
-                const int Ws = ups ? (W >> 1) : W;
+            const int csz = t_second ? C2 : C1;
+            if (t_src_dirty) {                  // first slab of a source: the pixel offsets in that source's channel count
 #pragma unroll
-                for (int i = 0; i < GA; ++i) {
-                    const int hh = (a_hw[i] & 0xffff) - 4 + t_kh, ww = (a_hw[i] >> 16) - 4 + t_kw;
-                    const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-                    const int hsrc = ups ? (hh >> 1) : hh, wsrc = ups ? (ww >> 1) : ww;
-                    const int kofs = (i & 1) ? kofs_o : kofs_e;
-                    va[i] = ok ? (((a_ib[i] + hsrc) * Ws + wsrc) * csz + kofs) * 2 : OOB_OFF;
-                }
+                for (int i = 0; i < GA; ++i) a_vb[i] = (a_px[i] * csz + ((i & 1) ? kofs_o : kofs_e)) * 2;
+                t_src_dirty = false;
+            }
+            if (t_dirty) {                      // first slab of a tap (a slab never straddles a tap or the two sources)
+                const int ups = p->ups;
+                const int Ws = ups ? (p->W >> 1) : p->W;
+                t_bit = 3 * t_kh + t_kw;
+                // nearest-2x source: tap k of a window whose origin has parity b reads source row / column (b + k) >> 1
+                t_re = ((ups ? t_kh >> 1 : t_kh) * Ws * csz) * 2;
+                t_ro = ((ups ? (t_kh + 1) >> 1 : t_kh) * Ws * csz) * 2;
+                t_ce = ((ups ? t_kw >> 1 : t_kw) * csz) * 2;
+                t_co = ((ups ? (t_kw + 1) >> 1 : t_kw) * csz) * 2;
                 t_dirty = false;
             }
             i_second = t_second;
@@ -480,15 +498,32 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             // K index of this slab in the weight rows (OHWI: tap-major, then source 1 | source 2 channels)
             const unsigned k0 = (unsigned)((t_kh * ks + t_kw) * (C1 + C2) + (t_second ? C1 : 0) + t_c);
             i_soffB = i_rowB + k0 * 2u;
-            t_c += BK;
-            if (t_c >= (t_second ? C2 : C1)) {          // next source or next tap
-                t_c = 0;
+            if (tap_inner) {
+                // the ks * ks taps of one 64-channel slab back to back: their windows are shifts of the same input rows, so the
+                // taps after the first hit L2 (tap-major order re-reads the input from the fabric once per tap: 3.8 - 7.7 x the
+                // algorithmic bytes on the convolutions, profiles/r03_gemm_traffic_by_shape.txt)
                 t_dirty = true;
-                if (!t_second && C2 > 0) {
-                    t_second = true;
-                } else {
-                    t_second = false;
-                    if (++t_kw == ks) { t_kw = 0; ++t_kh; }
+                if (++t_kw == ks) {
+                    t_kw = 0;
+                    if (++t_kh == ks) {
+                        t_kh = 0;
+                        t_c += BK;
+                        if (t_c >= csz) { t_c = 0; t_second = true; t_src_dirty = true; }      // (past source 2: the tile is done)
+                    }
+                }
+            } else {
+                t_c += BK;
+                if (t_c >= csz) {                           // next source or next tap
+                    t_c = 0;
+                    t_dirty = true;
+                    if (!t_second && C2 > 0) {
+                        t_second = true;
+                        t_src_dirty = true;
+                    } else {
+                        t_src_dirty = t_second;             // back to source 1 (two-source convolutions only)
+                        t_second = false;
+                        if (++t_kw == ks) { t_kw = 0; ++t_kh; }
+                    }
                 }
             }
         } else {
@@ -505,7 +540,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             const int kofs = (q & 1) ? kofs_o : kofs_e;             // wave * GA is even
             lptr_t dst = (lptr_t)(smem + i_sb + (wave * GA + q) * 1024);
             if constexpr (CONV) {
-                const int v = (i_tail && kofs >= ktail_from) ? OOB_OFF : va[q < GA ? q : 0];
+                const int mk = a_mk[q < GA ? q : 0];
+                const int dlt = ((mk & 512) ? t_ro : t_re) + ((mk & 1024) ? t_co : t_ce);
+                const bool in = ((mk >> t_bit) & 1) != 0 && !(i_tail && kofs >= ktail_from);
+                const int v = in ? a_vb[q < GA ? q : 0] + dlt : OOB_OFF;
                 if (i_second) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, dst, 16, v, (int)i_soffA, 0, 0);
                 } else {
@@ -706,7 +744,7 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     p.tiles_n = (int)(cols / 320);
     p.tiles_total = (int)(((p.M + bm - 1) / bm) * p.tiles_n);
     // option "pp_sched" (env VSX_PP_SCHED): PP_* bits (tile walk)
-    p.pp_flags = (int)(gemm_option("pp_sched") & PP_TILES_LINEAR);
+    p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_INNER));
     const bool conv = p.a_mode == 1;
     const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0);
 #define VSX_PP_CASE(TM_, CONV_, EPI_) \
