@@ -39,11 +39,19 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2, help='timed clips per rank')
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--frames', type=int, default=16)
+    ap.add_argument('--frames', type=int, default=0, help='frames per clip (default 16; 64 with --config 4)')
+    ap.add_argument('--exchange', default='auto', choices=('auto', 'kv', 'sites'), help='--config 4: FrameShard exchange')
+    ap.add_argument('--cpu-frames', type=int, default=2,
+                    help='frames of the CPU-baseline sample (a T = 16 step pair is ~5 min on 128 cores: '
+                         'profiles/r04_cpu_baseline_T16.json records one)')
     ap.add_argument('--latent', type=int, default=64)
     ap.add_argument('--ddim-steps', type=int, default=50)
-    ap.add_argument('--config', type=int, default=2, choices=(2, 3),
-                    help='BASELINE.json configs[1] (default; the headline: plain text embedding, no adapter, no '
+    ap.add_argument('--config', type=int, default=2, choices=(2, 3, 4),
+                    help='4 = BASELINE.json configs[3]: ONE 64-frame clip (--frames defaults to 64), its frame axis sharded '
+                         'over the --gpus ranks (videoswap_amd.distributed.FrameShard: all-to-all re-shard frames <-> sites '
+                         'around every motion module / all-gather of the temporal K|V over RCCL; strong scaling; on one '
+                         'GPU the whole clip runs unsharded).  2 = '
+                         'BASELINE.json configs[1] (default; the headline: plain text embedding, no adapter, no '
                          'controller) or configs[2]: the full swap path through VideoSwapPipeline.validation — AttentionStore '
                          'during the inversion, ED-LoRA merge + per-layer embeddings [2,16,77,768], adapter residuals for '
                          'the first half of the sampling steps, AttentionRefine + two SpatialBlenders (use_blend: true)')
@@ -60,7 +68,10 @@ def parse():
                          'carries the hipEvent brackets).  Off by default: the replay path has not been timed on '
                          'hardware yet (round 2 ran out of GPU minutes), so the headline number is the eager one')
     ap.add_argument('--no-graphs', action='store_true', help='(default) launch every kernel eagerly')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.frames == 0:
+        args.frames = 64 if args.config == 4 else 16
+    return args
 
 
 def build_pipeline(device, frames, swap=False):
@@ -153,7 +164,7 @@ def one_clip(pipe, data, ddim_steps, marks=None):
     return out
 
 
-def cpu_baseline(frames_sample=2, latent=64):
+def cpu_baseline(frames_sample=2, latent=(64, 64)):
     """The oracle (CPU port of the reference's PyTorch path, fp32) on the host cores, on a bounded sample of what one
     DDIM step pair costs (1 inversion step = a B=1 UNet forward, 1 CFG step = a B=2 forward): both
     forwards at the full SD-1.5 width and the same 64x64 latent with T = `frames_sample` frames (a full T=16 step pair is
@@ -170,20 +181,21 @@ def cpu_baseline(frames_sample=2, latent=64):
             torch.nn.init.normal_(p, std=0.02)
     txt = torch.randn(2, 77, 768)
     times = {}
+    lh, lw = latent
     with torch.no_grad():
-        x1 = torch.randn(1, 4, frames_sample, latent, latent)
+        x1 = torch.randn(1, 4, frames_sample, lh, lw)
         model(x1, torch.tensor(481), txt[:1])       # warm-up (allocator, thread pool, oneDNN primitive caches)
         for b in (1, 2):
-            x = torch.randn(b, 4, frames_sample, latent, latent)
+            x = torch.randn(b, 4, frames_sample, lh, lw)
             t0 = time.time()
             model(x, torch.tensor(481), txt[:b])
             times[b] = time.time() - t0
     evals_per_s = 3 * frames_sample / (times[1] + times[2])
     return evals_per_s, threads, (f'1 inversion step (UNet B=1) + 1 CFG step (UNet B=2) at T={frames_sample}, '
-                                  f'{latent}x{latent} latent, fp32, after 1 warm-up forward: {times[1]:.1f} s + {times[2]:.1f} s')
+                                  f'{lh}x{lw} latent, fp32, after 1 warm-up forward: {times[1]:.1f} s + {times[2]:.1f} s')
 
 
-def torch_rocm_baseline(device, frames=16, latent=64, repeats=2):
+def torch_rocm_baseline(device, frames=16, latent=(64, 64), repeats=2):
     """Second stated baseline: the SAME oracle module (plain PyTorch, the reference's GPU-style path: fp16 weights,
     torch-ROCm eager ops = rocBLAS / MIOpen / SDPA) on this GPU — 1 inversion step (B=1) + 1 CFG step (B=2) at the full
     T and latent, warm-up + median, extrapolated to the 50 + 50 steps (every step is identical work).  Runs AFTER the
@@ -196,7 +208,7 @@ def torch_rocm_baseline(device, frames=16, latent=64, repeats=2):
             torch.nn.init.normal_(p, std=0.02)
     model = model.half()
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 4, frames, latent, latent, generator=g).to(device, torch.float16)
+    x = torch.randn(2, 4, frames, latent[0], latent[1], generator=g).to(device, torch.float16)
     txt = torch.randn(2, 77, 768, generator=g).to(device, torch.float16)
 
     def pair():
@@ -217,18 +229,47 @@ def torch_rocm_baseline(device, frames=16, latent=64, repeats=2):
     return dt
 
 
+def long_clip_exchange(unet, shard, args, world, lh, lw):
+    """configs[3]: what a rank exchanges per UNet forward — expected (closed form) beside what FrameShard
+    counted over the timed clips, so that the first multi-GPU run can be checked against the design figure.
+    exchange='sites': every motion module re-shards its activation frames -> sites and back: 2 * (N-1)/N * B * f_local *
+    hw * C * 2 bytes per module; exchange='kv': every temporal attention receives the other ranks' K|V rows:
+    (N-1) * B * f_local * hw * 2C * 2 bytes per attention layer (two per motion module)."""
+    chans = list(getattr(unet.config, 'block_out_channels', (320, 640, 1280, 1280)))
+    f_local = args.frames // world
+    modules = []                                    # (sites, channels) of every motion module: 2 per down level, 3 per up level
+    for lvl, c in enumerate(chans):
+        hw = (lh >> lvl) * (lw >> lvl)
+        modules += [(hw, c)] * (2 + 3)
+    per_b = {'sites': sum(2 * (world - 1) / world * f_local * hw * c * 2 for hw, c in modules),
+             'kv': sum(2 * (world - 1) * f_local * hw * 2 * c * 2 for hw, c in modules)}
+    forwards = args.steps * args.ddim_steps * 2     # one B=1 and one B=2 forward per DDIM step pair
+    mean_b = 1.5
+    rec = {'ranks': world, 'frames_per_rank': f_local, 'mode': args.exchange,
+           'expected_bytes_per_rank_per_forward_B1': {k: round(v) for k, v in per_b.items()},
+           'expected_note': 'B = 2 forwards move twice as much; "auto" uses the site re-shard wherever a level\'s site count '
+                            'splits over the ranks (every level of a 64x64 latent up to 8 ranks)'}
+    if shard is not None:
+        rec['counted_bytes_per_rank_per_forward_mean'] = round(shard.bytes_gathered / max(forwards, 1))
+        key = 'kv' if args.exchange == 'kv' else 'sites'
+        rec['expected_mean_for_counted'] = round(per_b[key] * mean_b)
+        rec['backend'] = shard.backend
+    return rec
+
+
 def gemm_traffic(frames, latent):
     """HBM bytes per vsx_gemm_f16 launch from the PMC passes of tools/pmc_by_shape.sh — only if that file was measured
     on THIS build of the library (source digest) at the benchmark shape; a stale file is not a measurement."""
     from videoswap_amd.build import source_digest
     path = os.path.join(ROOT, 'profiles', 'gemm_hbm_traffic.json')
     if not os.path.exists(path) or frames != 16 or latent != 64:
-        return None, 'no PMC traffic file for this shape'
+        return None, None, 'no PMC traffic file for this shape'
     with open(path) as f:
         t = json.load(f)
     if t.get('lib_digest') != source_digest():
-        return None, f'PMC traffic file is from another build ({str(t.get("lib_digest"))[:12]})'
-    return round(t['hbm_bytes_per_launch']), f'{t["launches"]} launches of one inversion + one CFG step'
+        return None, None, f'PMC traffic file is from another build ({str(t.get("lib_digest"))[:12]})'
+    return (round(t['hbm_bytes_per_launch']), round(t.get('algorithmic_bytes_per_launch', 0)) or None,
+            f'{t["launches"]} launches of one inversion + one CFG step')
 
 
 def main():
@@ -250,11 +291,24 @@ def main():
     from videoswap_amd.distributed import max_over_ranks as max_over
     from videoswap_amd.synthetic import synthetic_clip
     swap = args.config == 3
+    longclip = args.config == 4
     lh, lw = args.latent_h or args.latent, args.latent_w or args.latent
     pipe = build_pipeline(device, args.frames, swap=swap)
-    # every rank owns different clips (seeded by rank); inputs resident in HBM before the timed region
-    clips = [synthetic_clip(seed=1000 * rank + i, frames=args.frames, height=lh, width=lw,
-                            device=device) for i in range(max(args.steps, 1))]
+    shard = None
+    if longclip:
+        # configs[3]: ONE clip for the whole job (same seed on every rank), rank r denoises frames [r*T/N, (r+1)*T/N)
+        clips = [synthetic_clip(seed=7000 + i, frames=args.frames, height=lh, width=lw, device=device)
+                 for i in range(max(args.steps, 1))]
+        if distributed:
+            from videoswap_amd.distributed import FrameShard
+            shard = FrameShard(args.frames, exchange=args.exchange)          # nccl process group -> the C-ABI collectives
+            shard.install(pipe.unet)
+            for c in clips:
+                c['latents'] = shard.local_slice(c['latents'])
+    else:
+        # every rank owns different clips (seeded by rank); inputs resident in HBM before the timed region
+        clips = [synthetic_clip(seed=1000 * rank + i, frames=args.frames, height=lh, width=lw,
+                                device=device) for i in range(max(args.steps, 1))]
     marks = []
     if swap:
         lora = synthetic_edlora(pipe.unet.state_dict())
@@ -280,6 +334,8 @@ def main():
     if graphs:
         pipe.unet._graphs.on_eager = (lambda on: ops.prof_pause(not on))
 
+    if shard is not None:
+        shard.bytes_gathered = 0
     ops.FlopCounter.reset(True)
     ops.prof_enable(args.prof_samples > 0, args.prof_samples, stride=1 if graphs else args.prof_stride)
     if graphs:
@@ -304,14 +360,19 @@ def main():
 
     elapsed = max_over(elapsed, device)              # whole-job time = slowest rank
 
-    frames_total = world * args.steps * args.frames
+    # clip-parallel: every rank its own clips (weak scaling); long clip: the ranks share ONE clip per step (strong scaling)
+    clips_job = args.steps if longclip else world * args.steps
+    frames_total = clips_job * args.frames
     value = frames_total / elapsed
     total_flop = (ops.FlopCounter.gemm + ops.FlopCounter.attention) * world
-    evals = world * args.steps * args.frames * 3 * args.ddim_steps          # (1 + 2) UNet frame-evals per DDIM step
+    evals = clips_job * args.frames * 3 * args.ddim_steps                   # (1 + 2) UNet frame-evals per DDIM step
     out = {
-        'metric': 'denoised frames/sec, 16-frame 512^2 clip @ 50 DDIM steps (end to end: inversion + CFG sampling)',
+        'metric': (f'denoised frames/sec, {args.frames}-frame 512^2 long clip @ 50 DDIM steps, frame axis sharded over the GPUs '
+                   '(end to end: inversion + CFG sampling)' if longclip else
+                   'denoised frames/sec, 16-frame 512^2 clip @ 50 DDIM steps (end to end: inversion + CFG sampling)'),
         'value': round(value, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 2), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 2), 'higher_is_better': True,
+        'scaling': 'strong' if longclip else 'weak',
         'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
         'config': {'launch': 'hip-graph' if graphs else 'eager',
                    'workload': (f'BASELINE.json configs[{args.config - 1}]: {args.frames}-frame {lw * 8}x{lh * 8} clip, SD-1.5 UNet3D + '
@@ -321,10 +382,12 @@ def main():
                                    'ED-LoRA merge + per-layer text embeddings [2,16,77,768], point-adapter residuals for '
                                    'sampling steps 0-25, AttentionRefine + latent / self-attention SpatialBlenders '
                                    '(use_blend), weights restored' if swap else '')),
-                   'latents': [1, 4, args.frames, lh, lw], 'parallelism': f'clip-parallel x{world}'},
+                   'latents': [1, 4, args.frames, lh, lw],
+                   'parallelism': (f'frame-sharded x{world} ({args.frames // world} frames per rank, exchange={args.exchange})'
+                                   if longclip else f'clip-parallel x{world}')},
         'readings': {'R1e_frames_per_s': round(value, 4),
                      # R1s: the guided-sampling half alone (frames / device time of the 50 CFG steps)
-                     'R1s_frames_per_s': round(frames_total / world / smp_s * world, 4) if smp_s > 0 else None,
+                     'R1s_frames_per_s': round(frames_total / smp_s, 4) if smp_s > 0 else None,
                      'inversion_s_per_clip': round(inv_s / max(args.steps, 1), 4),
                      'sampling_s_per_clip': round(smp_s / max(args.steps, 1), 4),
                      'R2_unet_frame_evals_per_s': round(evals / elapsed, 2),
@@ -333,14 +396,22 @@ def main():
                      'loop_mfma_frac': round(total_flop / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
                      'ceiling_R1e_at_100pct_mfma': 15.1},
     }
+    if longclip:
+        out['exchange'] = long_clip_exchange(pipe.unet, shard, args, world, lh, lw)
     if n_launch > 0 and gemm_ms > 0:
         ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-        traffic, traffic_note = gemm_traffic(args.frames, args.latent if (lh == lw == args.latent and not swap) else -1)
+        traffic, traffic_alg, traffic_note = gemm_traffic(
+            args.frames, args.latent if (lh == lw == args.latent and args.config == 2) else -1)
+        traffic_ratio = round(traffic / traffic_alg, 3) if traffic and traffic_alg else None
+        # footnote, not a roofline: what the power-managed clock sustains under chip-wide MFMA load on these boxes
+        out['readings']['gemm_tflops_vs_sustained_clock_peak'] = {
+            'peak_sustained': MFMA_SUSTAINED_TFLOPS, 'frac': round(ach / MFMA_SUSTAINED_TFLOPS, 4),
+            'source': 'core clock 1.75 GHz with all 256 CUs streaming MFMAs (tools/ubench/clock_probe.hip); the guide '
+                      'measures 2 495 TF dense, which is the peak the roofline object prices against'}
         out['roofline'] = {'bound': 'mfma', 'kernel': 'vsx_gemm_f16 (implicit-GEMM conv + GEMM, all shapes)',
                            'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_note,
-                           'peak_sustained': MFMA_SUSTAINED_TFLOPS, 'frac_of_sustained': round(ach / MFMA_SUSTAINED_TFLOPS, 4),
-                           'peak_sustained_source': 'core clock 1.75 GHz under chip-wide MFMA load (tools/ubench/clock_probe.hip)',
+                           'traffic_ratio': traffic_ratio, 'traffic_algorithmic': traffic_alg,
                            'launches_sampled': int(n_launch), 'sample_stride': args.prof_stride,
                            'sampling': ('all GEMM launches of every %d-th UNet call (eager); the other calls are '
                                         'HIP-graph replays' % args.prof_stride) if graphs else
@@ -350,7 +421,7 @@ def main():
                            'kernel_time_share_of_wall': round(gemm_ms * 1e-3 * args.prof_stride / (elapsed * 1.0), 4)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            evals_per_s, threads, sample = cpu_baseline()
+            evals_per_s, threads, sample = cpu_baseline(args.cpu_frames, (lh, lw))
             out['cpu_baseline'] = {'value': round(evals_per_s / (3 * args.ddim_steps), 6), 'unit': 'frames/s',
                                    'cores': threads, 'kind': 'port', 'sample': sample,
                                    'unet_frame_evals_per_s': round(evals_per_s, 4)}
@@ -360,7 +431,7 @@ def main():
         try:
             del pipe, clips
             torch.cuda.empty_cache()
-            pair_s = torch_rocm_baseline(device, args.frames, lh if lh == lw else args.latent)
+            pair_s = torch_rocm_baseline(device, args.frames, (lh, lw))
             out['torch_rocm_eager_fp16'] = {
                 'value': round(args.frames / (args.ddim_steps * pair_s), 4), 'unit': 'frames/s',
                 'sample': f'oracle module (plain PyTorch-ROCm eager, fp16) on the same GPU: 1 inversion step (B=1) + 1 CFG '

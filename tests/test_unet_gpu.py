@@ -117,14 +117,7 @@ def test_step_invariant_caches_follow_inputs_and_weights(setup):
     assert torch.equal(e, cold)
 
 
-import os  # noqa: E402
-
-GRAPHS = pytest.mark.skipif(os.environ.get('VSX_TEST_GRAPHS') != '1',
-                            reason='HIP-graph replay is opt-in until it has been timed on hardware (VSX_TEST_GRAPHS=1)')
-
-
 @pytest.mark.gpu
-@GRAPHS
 def test_hip_graph_replay_is_bit_identical_to_eager(setup):
     """The captured forward replays the same kernels on the same data layout: bit-identical outputs, across
     timesteps, texts, adapter residuals and a weight reload (which must drop the graph)."""
@@ -164,7 +157,6 @@ def test_hip_graph_replay_is_bit_identical_to_eager(setup):
 
 
 @pytest.mark.gpu
-@GRAPHS
 def test_hip_graphs_step_aside_for_controllers(setup):
     """Prompt-to-Prompt control processors keep host state per call: the graph path must not be taken."""
     from videoswap_amd import control

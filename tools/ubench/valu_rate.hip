@@ -11,7 +11,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int NCHAIN = 8, REP = 16;
 
 template <int MODE>
-__global__ __launch_bounds__(256) void probe(float* __restrict__ sink, long* __restrict__ cycles, int iters) {
+__global__ __launch_bounds__(1024) void probe(float* __restrict__ sink, long* __restrict__ cycles, int iters) {
     const int lane = threadIdx.x & 63;
     float v[NCHAIN];
     h2 hv[NCHAIN];
@@ -45,6 +45,9 @@ __global__ __launch_bounds__(256) void probe(float* __restrict__ sink, long* __r
                 if (MODE == 12) asm volatile("v_pk_max_f16 %0, %0, %0" : "+v"(hv[k]));              // v_pk_max_f16
                 if (MODE == 13) asm volatile("v_pk_add_u16 %0, %0, %0" : "+v"(hv[k]));              // v_pk_add_u16 (exponent arithmetic)
                 if (MODE == 14) asm volatile("v_ldexp_f32 %0, %0, 1" : "+v"(v[k]));                 // v_ldexp_f32
+                if (MODE == 15) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %1" : "=v"(hv[k]) : "v"(v[k]));  // round toward zero
+                if (MODE == 16) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[k]) : "v"(v[(k + 1) % NCHAIN]));
+                if (MODE == 17) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[k]) : "v"(v[(k + 1) % NCHAIN]));
             }
     }
     const long t1 = (long)__builtin_amdgcn_s_memtime();
@@ -54,16 +57,24 @@ __global__ __launch_bounds__(256) void probe(float* __restrict__ sink, long* __r
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// round 4: the same chains with 1, 2 and 4 waves per SIMD (workgroups of 256 / 512 / 1024 threads, one per CU).  One wave
+// alone cannot issue faster than one VALU instruction per ~5 cycles, whatever the instruction; what a kernel with several
+// waves per SIMD (flash attention: 4) pays per instruction is the SIMD's issue time = cycles / waves in the last column.
 template <int MODE>
 static void run(const char* name, float* sink, long* out_d) {
     const int grid = 256, iters = 2000;
-    probe<MODE><<<grid, 256>>>(sink, out_d, 100);
-    probe<MODE><<<grid, 256>>>(sink, out_d, iters);
-    std::vector<long> out(grid);
-    hipMemcpy(out.data(), out_d, grid * sizeof(long), hipMemcpyDeviceToHost);
-    long mx = 0;
-    for (long c : out) mx = c > mx ? c : mx;
-    printf("%-44s %6.2f cycles per wave64 instruction (one wave per SIMD)\n", name, (double)mx / ((double)iters * REP * NCHAIN));
+    printf("%-36s", name);
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        probe<MODE><<<grid, 256 * wps>>>(sink, out_d, 100);
+        probe<MODE><<<grid, 256 * wps>>>(sink, out_d, iters);
+        std::vector<long> out(grid);
+        hipMemcpy(out.data(), out_d, grid * sizeof(long), hipMemcpyDeviceToHost);
+        long mx = 0;
+        for (long c : out) mx = c > mx ? c : mx;
+        const double per = (double)mx / ((double)iters * REP * NCHAIN);
+        printf("  %d wave%s/SIMD: %5.2f per wave instr = %5.2f SIMD cycles each", wps, wps > 1 ? "s" : " ", per, per / wps);
+    }
+    printf("\n");
 }
 
 int main() {
@@ -78,7 +89,10 @@ int main() {
     run<13>("v_pk_add_u16", sink, out_d);
     run<10>("v_max3_f32", sink, out_d);
     run<14>("v_ldexp_f32", sink, out_d);
+    run<17>("v_mul_f32", sink, out_d);
+    run<16>("v_cndmask_b32", sink, out_d);
     run<7>("v_cvt_pk_f16_f32", sink, out_d);
+    run<15>("v_cvt_pkrtz_f16_f32", sink, out_d);
     run<1>("v_exp_f32", sink, out_d);
     run<5>("v_exp_f16", sink, out_d);
     run<2>("v_rcp_f32", sink, out_d);

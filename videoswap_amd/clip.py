@@ -16,7 +16,7 @@ import os
 import torch
 from torch import nn
 
-from . import ops
+from . import formats, ops
 from .compat import ModelMixin
 from .layers import LayerNorm, Linear
 
@@ -155,7 +155,7 @@ class CLIPTextModel(ModelMixin):
                     from safetensors.torch import load_file
                     state = load_file(file)
                 else:
-                    state = torch.load(file, map_location='cpu')
+                    state = formats.load_checkpoint(file)
                 break
         else:
             raise RuntimeError(f'no text-encoder weights under {path}')

@@ -20,6 +20,12 @@
 //      V^T tile [DT*32][72] halfs (144-byte rows = 9 slots, odd => conflict-free b128 reads).
 #include "common.h"
 
+#include <type_traits>
+
+namespace vsxg {
+long gemm_option(const char* name);      // gemm.hip: the option table of vsx_set_option
+}
+
 namespace {
 
 struct AttnParams {
@@ -46,7 +52,13 @@ constexpr int KV_TILE = 64;
 constexpr int VSTR = 72;          // V^T LDS row: 64 keys + one 16-byte dummy slot (odd slot count)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int D>
+// VAR: softmax instruction variants, A/B-ed on the GPU through the option "attn_var" (VSX_ATTN_VAR):
+//   bit 0: scale-and-subtract of two scores as one packed fp32 FMA (v_pk_fma_f32) instead of two v_fma_f32
+//   bit 1: P is rounded to fp16 toward zero (v_cvt_pkrtz_f16_f32) instead of to nearest (v_cvt_pk_f16_f32) — only where the
+//          softmax denominator is produced by the SAME rounded P (the ones row of the V^T tile, d = 40 / 80): a truncation's
+//          relative error is uniform on an interval as wide as a rounding's, and its mean cancels between the numerator
+//          and the denominator
+template <int D, int VAR = 0>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     constexpr int DK = (D + 15) / 16;   // k-steps of the QK^T product
     constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T
@@ -178,7 +190,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 #ifdef VSX_GEMM_TIMING
     long t_seg[6] = {0, 0, 0, 0, 0, 0}, t_last = (long)clock64();
 #endif
-    for (int j0 = 0; j0 < p.nk; j0 += KV_TILE, stage ^= 1) {
+    // One key tile.  MASKED (a compile-time constant) is the last, partial tile of a key count that is not a multiple of
+    // 64: with the test written as a run-time `if (j0 + KV_TILE > nk)` inside one loop body the compiler if-converted the
+    // mask — 31 compares, 33 selects and 37 key-index additions per tile in EVERY iteration, as many VALU instructions
+    // again as the softmax itself (32 fma, 32 exp, 16 cvt_pk, 20 max: ISA of round 3) — so the loop runs the unmasked
+    // body and the partial tile, if any, is peeled.
+    auto tile = [&](const int j0, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ASTAMP(0);
         __syncthreads();   // tile j0 is in LDS for every wave; the other slot is no longer being read
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         }
         ASTAMP(3);
         // ---- online softmax (lane-local per query column); VALU budget: max3, fma, exp2, cvt per score ----
-        if (j0 + KV_TILE > p.nk) {   // only the last, partial key tile needs masking (wave-uniform branch)
+        if constexpr (MASKED) {      // only the last, partial key tile needs masking
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -228,14 +246,28 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         }
         const float neg_m = -m_i;
         float rs = 0.f;
+        if constexpr ((VAR & 1) != 0) {
+            const vsx_f2 sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {neg_m, neg_m};
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], p.scale_log2e, neg_m));
-                s[kt][r] = e;
-                if (!HAS_SPARE) rs += e;
-            }
+                for (int r = 0; r < 16; r += 2) {
+                    const vsx_f2 t = vsx_f2{s[kt][r], s[kt][r + 1]} * sc2 + nm2;
+                    const float e0 = __builtin_amdgcn_exp2f(t[0]), e1 = __builtin_amdgcn_exp2f(t[1]);
+                    s[kt][r] = e0;
+                    s[kt][r + 1] = e1;
+                    if (!HAS_SPARE) rs += e0 + e1;
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], p.scale_log2e, neg_m));
+                    s[kt][r] = e;
+                    if (!HAS_SPARE) rs += e;
+                }
+        }
         if (!HAS_SPARE) {
             rs += __shfl_xor(rs, 32, 64);
             l_i += rs;
@@ -249,8 +281,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 h8 pf;
+                if constexpr ((VAR & 2) != 0 && HAS_SPARE) {
+                    unsigned w[4];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)s[kt][8 * s2 + jj];
+                    for (int jj = 0; jj < 4; ++jj)
+                        w[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s[kt][8 * s2 + 2 * jj],
+                                                                                        s[kt][8 * s2 + 2 * jj + 1]));
+                    pf = as_h8(make_uint4(w[0], w[1], w[2], w[3]));
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)s[kt][8 * s2 + jj];
+                }
                 const int c0 = kt * 32 + 16 * s2 + 8 * hi;
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
@@ -260,6 +301,12 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
             }
         }
         ASTAMP(5);
+        stage ^= 1;
+    };
+    {
+        int j0 = 0;
+        for (; j0 + KV_TILE <= p.nk; j0 += KV_TILE) tile(j0, std::false_type{});
+        if (j0 < p.nk) tile(j0, std::true_type{});
     }
 
 #ifdef VSX_GEMM_TIMING
@@ -298,9 +345,16 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 }
 
 template <int D>
-int launch_attn(const AttnParams& p, long nb, hipStream_t stream) {
+int launch_attn(const AttnParams& p, long nb, hipStream_t stream, const int var = 0) {
     dim3 grid((unsigned)(((p.nq + 127) / 128) * (long)p.heads * nb));
-    hipLaunchKernelGGL((flash_attn_kernel<D>), grid, dim3(256), 0, stream, p);
+    if constexpr (D == 40 || D == 80) {        // the variants exist for the head dims of the big launches only
+        if (var == 1) hipLaunchKernelGGL((flash_attn_kernel<D, 1>), grid, dim3(256), 0, stream, p);
+        else if (var == 2) hipLaunchKernelGGL((flash_attn_kernel<D, 2>), grid, dim3(256), 0, stream, p);
+        else if (var == 3) hipLaunchKernelGGL((flash_attn_kernel<D, 3>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((flash_attn_kernel<D, 0>), grid, dim3(256), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((flash_attn_kernel<D, 0>), grid, dim3(256), 0, stream, p);
+    }
     return vsx_check_launch("vsx_attention_f16");
 }
 
@@ -761,9 +815,9 @@ extern "C" int vsx_attention_f16(const void* Q, const void* K, const void* VT, v
         case 8: return launch_attn<8>(p, nb, stream);
         case 16: return launch_attn<16>(p, nb, stream);
         case 32: return launch_attn<32>(p, nb, stream);
-        case 40: return launch_attn<40>(p, nb, stream);
+        case 40: return launch_attn<40>(p, nb, stream, (int)vsxg::gemm_option("attn_var"));
         case 64: return launch_attn<64>(p, nb, stream);
-        case 80: return launch_attn<80>(p, nb, stream);
+        case 80: return launch_attn<80>(p, nb, stream, (int)vsxg::gemm_option("attn_var"));
         case 128: return launch_attn<128>(p, nb, stream);
         case 160: return launch_attn<160>(p, nb, stream);
         default: return vsx_fail(VSX_E_UNSUPPORTED, "attention: head dim %ld not in {8,16,32,40,64,80,128,160}", (long)d);

@@ -110,8 +110,9 @@ def load_new_concept(pipe, new_concept_embedding, enable_edlora=True):
 def merge_lora_into_weight(original_state_dict, lora_state_dict, model_type, alpha, touched=None):
     """convert_edlora_to_diffusers.py:36-79: W += alpha * (up @ down) for every key that has LoRA factors.  Same values as
     the reference's result; the reference deep-copies the whole state dict first (2.5 GB for the UNet) — here the entries
-    without LoRA factors stay references to the caller's tensors, the merged ones are new tensors.  `touched` (a list)
-    receives the merged keys."""
+    without LoRA factors stay references to the caller's tensors (ALIASES of the live model's parameters when the caller
+    passed `model.state_dict()`: a converter that edits the result in place must clone those entries first), the merged
+    ones are new tensors.  `touched` (a list) receives the merged keys."""
     assert model_type in ('unet', 'text_encoder')
     keys = UNET_LORA_KEYS if model_type == 'unet' else TEXT_LORA_KEYS
     merged = dict(original_state_dict)

@@ -16,7 +16,7 @@ from . import ops
 
 
 class _Entry:
-    __slots__ = ('graph', 'sample', 'semb', 'text', 'residuals', 'out', 'flop_gemm', 'flop_attention')
+    __slots__ = ('graph', 'sample', 'semb', 'text', 'residuals', 'out', 'flop_gemm', 'flop_attention', 'keep')
 
 
 class GraphCache:
@@ -70,6 +70,7 @@ class GraphCache:
 
     def _capture(self, unet, sample, silu_emb, text, residuals):
         e = _Entry()
+        e.keep = None
         e.sample, e.semb, e.text = sample.clone(), silu_emb.clone(), text.clone()
         e.residuals = None if residuals is None else [r.clone() for r in residuals]
         # one eager pass on a side stream first: every kernel's one-time host setup (LDS size attributes, device
@@ -88,6 +89,8 @@ class GraphCache:
             e.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(e.graph):
                 e.out = unet._forward_body(e.sample, e.semb, e.text, e.residuals)
+            # the graph's kernel arguments point at the folded LayerNorm operands of ops._fold_cache: hold them
+            e.keep = ops.fold_cache_tensors()
         finally:
             e.flop_gemm, e.flop_attention = fc.gemm, fc.attention
             fc.enabled, fc.gemm, fc.attention = saved

@@ -157,17 +157,30 @@ class DeferredLN:
         return y.view(self.x.shape)
 
 
-_fold_cache = {}      # (id(weight), id(gamma)) -> (stamp, weight ref, W o gamma, c1, c2); pe products hang off the entry
+_fold_cache = {}      # (id(weight), id(gamma)) -> (stamp, weight ref, W o gamma, c1, c2, {pe products}, gamma ref)
+
+
+def fold_cache_tensors():
+    """Every folded operand alive right now.  A captured HIP graph bakes their addresses into its kernel arguments:
+    graphs.GraphCache keeps this list with the graph entry, so the memory outlives any eviction here."""
+    out = []
+    for hit in _fold_cache.values():
+        out.extend((hit[2], hit[3], hit[4]))
+        out.extend(hit[5].values())
+    return out
 
 
 def _ln_folded(weight, bias, ln):
     """W' = W o gamma (fp16, the B operand), c1[n] = sum_k W'[n, k] (fp32), c2 = beta W^T + b (fp16, the epilogue bias);
-    rebuilt when any of the parameters changes (LoRA merge / load_state_dict bump the version)."""
+    rebuilt when any of the parameters changes (LoRA merge / load_state_dict bump the version).  An entry lives exactly as
+    long as its weight tensor (a finalizer on the weight evicts it: the fused-projection tensors that a LoRA merge
+    rebuilds do not leave stale folded copies behind, and nothing is ever dropped while its weight — and therefore a
+    graph captured over it — can still be used)."""
     import weakref
     key = (id(weight), id(ln.gamma))
     stamp = tuple((t.data_ptr(), t._version) for t in (weight, ln.gamma, ln.beta) + ((bias,) if bias is not None else ()))
     hit = _fold_cache.get(key)
-    if hit is None or hit[0] != stamp or hit[1]() is not weight:
+    if hit is None or hit[0] != stamp or hit[1]() is not weight or hit[6]() is not ln.gamma:
         with torch.no_grad():
             w32 = weight.detach().reshape(weight.shape[0], -1).float()
             wf = (w32 * ln.gamma.detach().float()[None, :]).to(_F16).contiguous()
@@ -176,10 +189,11 @@ def _ln_folded(weight, bias, ln):
             if bias is not None:
                 c2 = c2 + bias.detach().float()
             c2 = c2.to(_F16).contiguous()
-        if len(_fold_cache) > 4096:
-            _fold_cache.clear()
-        hit = (stamp, weakref.ref(weight), wf, c1, c2, {})
+        fresh = hit is None or hit[1]() is not weight
+        hit = (stamp, weakref.ref(weight), wf, c1, c2, {}, weakref.ref(ln.gamma))
         _fold_cache[key] = hit
+        if fresh:
+            weakref.finalize(weight, _fold_cache.pop, key, None)
     return hit
 
 
@@ -789,6 +803,10 @@ def _publish(name):
                 else:
                     return _raw[name](*args, **kwargs)
             from . import autograd
+            # the gradient path works on plain tensors: a LayerNorm deferred into this consumer (its own input had no
+            # gradient, e.g. unfrozen weights under grad mode) is applied by its standalone kernel first
+            if args and isinstance(args[0], DeferredLN):
+                args = (args[0].materialize(),) + tuple(args[1:])
             return autograd.dispatch(name, *args, **kwargs)
         return _raw[name](*args, **kwargs)
 

@@ -16,7 +16,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 
 import torch
 
-from . import ops
+from . import formats, ops
 from .compat import PIPELINE_REGISTRY, BaseOutput, DDIMInverseScheduler
 from .control import AttentionStore, EmptyControl, make_controller, register_attention_control
 from .edlora import (convert_edlora, encode_edlora_prompt, revise_edlora_unet_attention_forward)
@@ -359,7 +359,7 @@ class VideoSwapPipeline:
             if lora_path is not None:
                 lora_path, lora_alpha = lora_path.split('---')
                 enable_edlora = 'edlora' in lora_path
-                state = (lora_loader or (lambda p: torch.load(p, map_location='cpu')))(lora_path)
+                state = (lora_loader or formats.load_checkpoint)(lora_path)
                 _, new_concept_cfg = convert_edlora(self, state, enable_edlora=enable_edlora, alpha=float(lora_alpha),
                                                     snapshot=pretrained)
                 if enable_edlora:

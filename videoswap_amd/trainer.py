@@ -105,17 +105,24 @@ class VideoSwapTrainer(VideoSwapPipeline):
         # FIXED parameter list (missing gradients as zeros) are averaged first, finiteness is tested on the reduced
         # buffer — an inf / nan on one rank reaches all of them through the sum
         params = [p for p in self.adapter.parameters() if p.requires_grad]
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+        # ... followed by one has-gradient flag per parameter: a parameter that took part in the loss on NO rank keeps
+        # p.grad = None, so that an optimizer with weight decay / momentum skips it as it would on one GPU
+        has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], dtype=torch.float32, device=params[0].device)
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params]
+                         + [has])
         self._all_reduce_mean(flat)
+        has = flat[-len(params):] > 0
+        flat = flat[:-len(params)]
         finite = bool(torch.isfinite(flat).all())
         if finite:
             flat.mul_(1.0 / self.loss_scale)
             o = 0
-            for p in params:
+            for p, h in zip(params, has.tolist()):
                 n = p.numel()
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(flat[o:o + n].view_as(p))
+                if h:
+                    if p.grad is None:
+                        p.grad = torch.empty_like(p)
+                    p.grad.copy_(flat[o:o + n].view_as(p))
                 o += n
             # trainer_videoswap.py:96-97 clips the UNet's parameters, which have no gradient: kept as the no-op it is
             self.optimizer.step()

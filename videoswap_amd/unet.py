@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import torch
 from torch import nn
 
-from . import ops
+from . import formats, ops
 from .attention import Attention, VanillaAttentionProcessor
 from .compat import MODEL_REGISTRY, BaseOutput, ConfigMixin, ModelMixin, register_to_config
 from .layers import (FeedForward, GroupNorm, InflatedConv3d, LayerNorm, Linear, PointwiseConv, StepInvariantCache,
@@ -773,7 +773,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         model_file = os.path.join(pretrained_model_path, 'diffusion_pytorch_model.bin')
         if not os.path.isfile(model_file):
             raise RuntimeError(f'{model_file} does not exist')
-        state_dict = torch.load(model_file, map_location='cpu')
+        state_dict = formats.load_checkpoint(model_file)
         missing, unexpected = model.load_state_dict(state_dict, strict=False)
         print(f'### missing keys: {len(missing)}; \n### unexpected keys: {len(unexpected)};')
         params = [p.numel() if 'temporal' in n else 0 for n, p in model.named_parameters()]

@@ -18,7 +18,7 @@ from dataclasses import dataclass
 import torch
 from torch import nn
 
-from . import ops
+from . import formats, ops
 from .compat import BaseOutput, ConfigMixin, ModelMixin, register_to_config
 from .layers import GroupNorm, InflatedConv3d as Conv2d, Linear
 
@@ -286,7 +286,7 @@ class AutoencoderKL(ModelMixin, ConfigMixin):
             from safetensors.torch import load_file
             state = load_file(st_file)
         elif os.path.isfile(bin_file):
-            state = torch.load(bin_file, map_location='cpu')
+            state = formats.load_checkpoint(bin_file)
         else:
             raise RuntimeError(f'no VAE weights under {path}')
         model.load_state_dict(state, strict=True)
