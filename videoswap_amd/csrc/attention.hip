@@ -58,7 +58,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //          softmax denominator is produced by the SAME rounded P (the ones row of the V^T tile, d = 40 / 80): a truncation's
 //          relative error is uniform on an interval as wide as a rounding's, and its mean cancels between the numerator
 //          and the denominator
-template <int D, int VAR = 0>
+//
+// QB: 32-query column blocks per wave.  The round-4 A/B (profiles/r04_attn_ab.txt) showed that halving the softmax's VALU
+// instruction count changes nothing at d = 40: the kernel streams 16 KB of K / V^T per 128 queries and 64 keys into LDS,
+// 0.0089 B per MFMA FLOP, i.e. ~8 TB/s chip-wide at its 640 TF/s — the L2 -> LDS delivery rate that also caps the GEMM
+// main loop.  With QB = 2 a wave owns 64 queries: every K and V^T fragment read from LDS feeds two
+// MFMAs, a workgroup covers 256 queries per tile, and both the bytes delivered into LDS and the LDS fragment reads per
+// FLOP halve (128 accumulator + 64 score registers: two waves per SIMD instead of four).
+template <int D, int VAR = 0, int QB = 1>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     constexpr int DK = (D + 15) / 16;   // k-steps of the QK^T product
     constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T
@@ -89,23 +96,26 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         const int xcd = wg & 7, local = wg >> 3;
         wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + local;
     }
-    const int qtiles = (p.nq + 127) / 128;
+    constexpr int QTILE = 128 * QB;      // queries per workgroup
+    const int qtiles = (p.nq + QTILE - 1) / QTILE;
     const int qt = wg % qtiles;
     const int h = (wg / qtiles) % p.heads;
     const long b = wg / (qtiles * p.heads);
     const long kvb = b / p.kv_div;
 
-    const int q = qt * 128 + wave * 32 + l31;
-    const bool qok = q < p.nq;
+    const int q0 = qt * QTILE + wave * (32 * QB) + l31;      // query of column block 0; block x: q0 + 32 x
 
     // Q fragments: B operand of S^T = K Q^T; lane (q, hi) holds Q[q, t*16 + hi*8 .. +7]
-    h8 qf[DK];
-    {
+    h8 qf[QB][DK];
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+        const int q = q0 + 32 * x;
+        const bool qok = q < p.nq;
         const half_t* qrow = p.Q + b * p.q_bs + (long)(qok ? q : 0) * p.ldq + h * D;
 #pragma unroll
         for (int t = 0; t < DK; ++t) {
             const int d0 = t * 16 + hi * 8;
-            qf[t] = (qok && d0 < D) ? as_h8(ld16(qrow + d0)) : as_h8(make_uint4(0, 0, 0, 0));
+            qf[x][t] = (qok && d0 < D) ? as_h8(ld16(qrow + d0)) : as_h8(make_uint4(0, 0, 0, 0));
         }
     }
 
@@ -177,13 +187,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
             }
     };
 
-    f16v o[DT];
+    f16v o[QB][DT];
+    float m_i[QB], l_i[QB];
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int x = 0; x < QB; ++x) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-    float m_i = -INFINITY;
-    float l_i = 0.f;
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[x][t][r] = 0.f;
+        m_i[x] = -INFINITY;
+        l_i[x] = 0.f;
+    }
 
     issue(0, 0);
     int stage = 0;
@@ -206,8 +220,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         const half_t* sK = reinterpret_cast<const half_t*>(smem + stage * STAGE);
         const half_t* sV = reinterpret_cast<const half_t*>(smem + stage * STAGE + K_BYTES);
 
-        // ---- S^T = K Q^T : two 32-key row tiles ----
-        f16v s[2];
+        // ---- S^T = K Q^T : two 32-key row tiles; a K fragment feeds the QB query blocks ----
+        f16v s[QB][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const half_t* krow = sK + (kt * 32 + l31) * KSTR + hi * 8;
@@ -215,88 +229,97 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int t = 0; t < DK; ++t) {
                 const h8 kf = *reinterpret_cast<const h8*>(krow + t * 16);
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t], t == 0 ? zero : s[kt], 0, 0, 0);
+#pragma unroll
+                for (int x = 0; x < QB; ++x)
+                    s[x][kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[x][t], t == 0 ? zero : s[x][kt], 0, 0, 0);
             }
         }
         ASTAMP(3);
         // ---- online softmax (lane-local per query column); VALU budget: max3, fma, exp2, cvt per score ----
-        if constexpr (MASKED) {      // only the last, partial key tile needs masking
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+        for (int x = 0; x < QB; ++x) {
+            if constexpr (MASKED) {      // only the last, partial key tile needs masking
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // C/D row (r&3) + 8*(r>>2) + 4*hi of the tile holds key (r&3) + 4*((r>>2)&1) + 8*hi + 16*(r>>3)
-                    const int key = j0 + kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
-                    if (key >= p.nk) s[kt][r] = -INFINITY;
-                }
-        }
-        float mx = fmaxf(s[0][0], s[1][0]);
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2e;      // scale > 0: max commutes with the scaling
-        if (!__all(mx <= m_i)) {     // running max grows: rescale O (and the denominator row inside it)
-            const float m_new = fmaxf(m_i, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-            m_i = m_new;
-            if (!HAS_SPARE) l_i *= alpha;
+                    for (int r = 0; r < 16; ++r) {
+                        // C/D row (r&3) + 8*(r>>2) + 4*hi of the tile holds key (r&3) + 4*((r>>2)&1) + 8*hi + 16*(r>>3)
+                        const int key = j0 + kt * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
+                        if (key >= p.nk) s[x][kt][r] = -INFINITY;
+                    }
+            }
+            float mx = fmaxf(s[x][0][0], s[x][1][0]);
 #pragma unroll
-            for (int t = 0; t < DT; ++t)
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[x][0][r]), s[x][1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2e;      // scale > 0: max commutes with the scaling
+            if (!__all(mx <= m_i[x])) {     // running max grows: rescale O (and the denominator row inside it)
+                const float m_new = fmaxf(m_i[x], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_i[x] - m_new);
+                m_i[x] = m_new;
+                if (!HAS_SPARE) l_i[x] *= alpha;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
-        }
-        const float neg_m = -m_i;
-        float rs = 0.f;
-        if constexpr ((VAR & 1) != 0) {
-            const vsx_f2 sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {neg_m, neg_m};
+                for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                    for (int r = 0; r < 16; ++r) o[x][t][r] *= alpha;
+            }
+            const float neg_m = -m_i[x];
+            float rs = 0.f;
+            if constexpr ((VAR & 1) != 0) {
+                const vsx_f2 sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {neg_m, neg_m};
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const vsx_f2 t = vsx_f2{s[kt][r], s[kt][r + 1]} * sc2 + nm2;
-                    const float e0 = __builtin_amdgcn_exp2f(t[0]), e1 = __builtin_amdgcn_exp2f(t[1]);
-                    s[kt][r] = e0;
-                    s[kt][r + 1] = e1;
-                    if (!HAS_SPARE) rs += e0 + e1;
-                }
-        } else {
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                    for (int r = 0; r < 16; r += 2) {
+                        const vsx_f2 t = vsx_f2{s[x][kt][r], s[x][kt][r + 1]} * sc2 + nm2;
+                        const float e0 = __builtin_amdgcn_exp2f(t[0]), e1 = __builtin_amdgcn_exp2f(t[1]);
+                        s[x][kt][r] = e0;
+                        s[x][kt][r + 1] = e1;
+                        if (!HAS_SPARE) rs += e0 + e1;
+                    }
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], p.scale_log2e, neg_m));
-                    s[kt][r] = e;
-                    if (!HAS_SPARE) rs += e;
-                }
-        }
-        if (!HAS_SPARE) {
-            rs += __shfl_xor(rs, 32, 64);
-            l_i += rs;
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[x][kt][r], p.scale_log2e, neg_m));
+                        s[x][kt][r] = e;
+                        if (!HAS_SPARE) rs += e;
+                    }
+            }
+            if (!HAS_SPARE) {
+                rs += __shfl_xor(rs, 32, 64);
+                l_i[x] += rs;
+            }
         }
 
         ASTAMP(4);
-        // ---- O^T += V^T P^T ----
+        // ---- O^T += V^T P^T; a V^T fragment feeds the QB query blocks ----
         // B operand k-slot jj of (kt, s2) on lane hi carries key kt*32 + 16*s2 + 8*hi + jj (K rows are permuted)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                h8 pf;
-                if constexpr ((VAR & 2) != 0 && HAS_SPARE) {
-                    unsigned w[4];
+                h8 pf[QB];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        w[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s[kt][8 * s2 + 2 * jj],
-                                                                                        s[kt][8 * s2 + 2 * jj + 1]));
-                    pf = as_h8(make_uint4(w[0], w[1], w[2], w[3]));
-                } else {
+                for (int x = 0; x < QB; ++x) {
+                    if constexpr ((VAR & 2) != 0 && HAS_SPARE) {
+                        unsigned w[4];
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (half_t)s[kt][8 * s2 + jj];
+                        for (int jj = 0; jj < 4; ++jj)
+                            w[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s[x][kt][8 * s2 + 2 * jj],
+                                                                                            s[x][kt][8 * s2 + 2 * jj + 1]));
+                        pf[x] = as_h8(make_uint4(w[0], w[1], w[2], w[3]));
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 8; ++jj) pf[x][jj] = (half_t)s[x][kt][8 * s2 + jj];
+                    }
                 }
                 const int c0 = kt * 32 + 16 * s2 + 8 * hi;
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
                     const h8 vf = *reinterpret_cast<const h8*>(sV + (t * 32 + l31) * VSTR + c0);
-                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
+#pragma unroll
+                    for (int x = 0; x < QB; ++x) o[x][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[x], o[x][t], 0, 0, 0);
                 }
             }
         }
@@ -315,32 +338,35 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         for (int k = 0; k < 6; ++k) o_dbg[k] = t_seg[k];
     }
 #endif
-    if (HAS_SPARE) {
-        // the denominator sits in the last row (31) of the last O^T tile: register 15 of the lanes with hi == 1;
-        // broadcast it to the lane pair
-        constexpr int reg = 15;
-        constexpr int owner_hi = 1;
-        const float mine = o[DT - 1][reg];
-        const float other = __shfl_xor(mine, 32, 64);
-        l_i = (hi == owner_hi) ? mine : other;
-    }
-
-    // ---- normalise and store: lane (q, hi) holds O[q, t*32 + 8*g + 4*hi + 0..3] ----
-    if (qok) {
-        const float inv = 1.0f / l_i;
-        half_t* orow = p.O + b * p.o_bs + (long)q * p.ldo + h * D;
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+    for (int x = 0; x < QB; ++x) {
+        if (HAS_SPARE) {
+            // the denominator sits in the last row (31) of the last O^T tile: register 15 of the lanes with hi == 1;
+            // broadcast it to the lane pair
+            constexpr int reg = 15;
+            constexpr int owner_hi = 1;
+            const float mine = o[x][DT - 1][reg];
+            const float other = __shfl_xor(mine, 32, 64);
+            l_i[x] = (hi == owner_hi) ? mine : other;
+        }
+        // ---- normalise and store: lane (q, hi) holds O[q, t*32 + 8*g + 4*hi + 0..3] ----
+        const int q = q0 + 32 * x;
+        if (q < p.nq) {
+            const float inv = 1.0f / l_i[x];
+            half_t* orow = p.O + b * p.o_bs + (long)q * p.ldo + h * D;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = t * 32 + 8 * g + 4 * hi;
-                if (c < D) {
-                    h4 pk;
+            for (int t = 0; t < DT; ++t)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g + e] * inv);
-                    *reinterpret_cast<h4*>(orow + c) = pk;
+                for (int g = 0; g < 4; ++g) {
+                    const int c = t * 32 + 8 * g + 4 * hi;
+                    if (c < D) {
+                        h4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[x][t][4 * g + e] * inv);
+                        *reinterpret_cast<h4*>(orow + c) = pk;
+                    }
                 }
-            }
+        }
     }
 }
 
@@ -348,9 +374,15 @@ template <int D>
 int launch_attn(const AttnParams& p, long nb, hipStream_t stream, const int var = 0) {
     dim3 grid((unsigned)(((p.nq + 127) / 128) * (long)p.heads * nb));
     if constexpr (D == 40 || D == 80) {        // the variants exist for the head dims of the big launches only
-        if (var == 1) hipLaunchKernelGGL((flash_attn_kernel<D, 1>), grid, dim3(256), 0, stream, p);
-        else if (var == 2) hipLaunchKernelGGL((flash_attn_kernel<D, 2>), grid, dim3(256), 0, stream, p);
-        else if (var == 3) hipLaunchKernelGGL((flash_attn_kernel<D, 3>), grid, dim3(256), 0, stream, p);
+        // attn_var bit 2 (4): 64 queries per wave (QB = 2) where a launch still has >= 2 workgroups per CU that way
+        const long wg2 = ((p.nq + 255) / 256) * (long)p.heads * nb;
+        if ((var & 4) != 0 && ((wg2 >= 512 && p.nq >= 256) || (var & 8) != 0)) {       // bit 3 (8): whatever the size (tests)
+            dim3 grid2((unsigned)wg2);
+            if (var & 2) hipLaunchKernelGGL((flash_attn_kernel<D, 2, 2>), grid2, dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((flash_attn_kernel<D, 0, 2>), grid2, dim3(256), 0, stream, p);
+        } else if ((var & 3) == 1) hipLaunchKernelGGL((flash_attn_kernel<D, 1>), grid, dim3(256), 0, stream, p);
+        else if ((var & 3) == 2) hipLaunchKernelGGL((flash_attn_kernel<D, 2>), grid, dim3(256), 0, stream, p);
+        else if ((var & 3) == 3) hipLaunchKernelGGL((flash_attn_kernel<D, 3>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((flash_attn_kernel<D, 0>), grid, dim3(256), 0, stream, p);
     } else {
         hipLaunchKernelGGL((flash_attn_kernel<D, 0>), grid, dim3(256), 0, stream, p);

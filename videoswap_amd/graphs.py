@@ -75,10 +75,19 @@ class GraphCache:
         e.residuals = None if residuals is None else [r.clone() for r in residuals]
         # one eager pass on a side stream first: every kernel's one-time host setup (LDS size attributes, device
         # queries, split-K workspace growth) must have happened before the capture
+        from .layers import StepInvariantCache
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            unet._forward_body(e.sample, e.semb, e.text, e.residuals)
+        # no step-invariant host cache may answer for the static buffers: a projection cached on `e.semb` / `e.text` by the
+        # warm-up pass would be missing from the captured graph, and every replay would reuse the first call's time-
+        # embedding and text projections (found when the graph tests joined the default GPU suite in round 4)
+        StepInvariantCache.bypass = True
+        try:
+            with torch.cuda.stream(side):
+                unet._forward_body(e.sample, e.semb, e.text, e.residuals)
+        except BaseException:
+            StepInvariantCache.bypass = False
+            raise
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.prof_pause(True)          # hipEvent pairs cannot be recorded inside a capture
@@ -92,6 +101,7 @@ class GraphCache:
             # the graph's kernel arguments point at the folded LayerNorm operands of ops._fold_cache: hold them
             e.keep = ops.fold_cache_tensors()
         finally:
+            StepInvariantCache.bypass = False
             e.flop_gemm, e.flop_attention = fc.gemm, fc.attention
             fc.enabled, fc.gemm, fc.attention = saved
             ops.prof_pause(False)
