@@ -443,6 +443,29 @@ def test_attention_self(nb, heads, nq, nk, d):
     assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
 
 
+@pytest.mark.parametrize('qb', [1, 2])
+@pytest.mark.parametrize('nb,heads,nq,nk,d,kv_div', [(2, 8, 300, 300, 40, 1), (2, 8, 1024, 1001, 40, 1), (4, 8, 260, 77, 80, 2),
+                                                     (1, 8, 336, 336, 80, 1)])
+def test_attention_query_blocks_per_wave(qb, nb, heads, nq, nk, d, kv_div):
+    """32 / 64 queries per wave (option attn_qb; the launch rule takes 64 only for the big self-attention launches, so both
+    are forced here): ragged query tiles (300 = 256 + 44), a ragged key count (1001: the peeled partial tile), shared text
+    K / V.  The two forms must also agree with each other far inside the tolerance (same arithmetic per query)."""
+    C = heads * d
+    q = rnd(nb, nq, C, seed=131)
+    k, v = rnd(nb // kv_div, nk, C, seed=132), rnd(nb // kv_div, nk, C, seed=133)
+    scale = d ** -0.5
+    ref, _ = attn_ref(q, k, v, heads, scale, kv_div=kv_div)
+    try:
+        ops().set_option('attn_qb', qb)
+        out = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
+        ops().set_option('attn_qb', 3 - qb)
+        other = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
+    finally:
+        ops().set_option('attn_qb', 0)
+    assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
+    assert torch.equal(out, other), 'a query\'s result must not depend on how many query blocks its wave owns'
+
+
 def test_attention_self_benchmark_shape():
     """N = 4096, d = 40, 8 heads: the 64x64-level self-attention of the benchmarked model (32 query tiles per head,
     XCD-ordered workgroups); nb = 4 keeps the fp32 reference's score tensor at 2 GiB."""

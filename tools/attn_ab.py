@@ -1,4 +1,4 @@
-"""A/B of the flash-attention softmax variants (option attn_var, csrc/attention.hip) at the UNet's self-attention shapes:
+"""A/B of flash attention with 32 / 64 queries per wave (option attn_qb, csrc/attention.hip) at the UNet's self-attention shapes:
 interleaved rounds in ONE process, median per variant, and each variant's error against an fp32 PyTorch reference on a
 smaller problem of the same head dim.
 
@@ -39,7 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--reps', type=int, default=3)
-    ap.add_argument('--vars', default='0,1,2,3')
+    ap.add_argument('--vars', default='1,2', help='values of the option attn_qb (query blocks per wave)')
     args = ap.parse_args()
     variants = [int(v) for v in args.vars.split(',')]
     print(f'# flash attention, median of {args.rounds} rounds x {args.reps} launches; us per launch, TFLOP/s of 4*nb*heads*n*n*d')
@@ -48,16 +48,16 @@ def main():
         fn = lambda: ops.attention(q, k, vt, heads, d ** -0.5)      # noqa: E731
         ts = {x: [] for x in variants}
         for x in variants:
-            ops.set_option('attn_var', x)
+            ops.set_option('attn_qb', x)
             fn()
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for x in variants:
-                ops.set_option('attn_var', x)
+                ops.set_option('attn_qb', x)
                 ts[x].append(time_once(fn, args.reps))
         flop = 4.0 * nb * heads * n * n * d
         med = {x: sorted(t)[len(t) // 2] * 1000.0 for x, t in ts.items()}
-        print(f'nb={nb:3d} n={n:5d} d={d:3d}  ' + '  '.join(f'var{x}: {med[x]:8.1f} us {flop / med[x] / 1e6:7.1f} TF/s' for x in variants),
+        print(f'nb={nb:3d} n={n:5d} d={d:3d}  ' + '  '.join(f'qb{x}: {med[x]:8.1f} us {flop / med[x] / 1e6:7.1f} TF/s' for x in variants),
               flush=True)
     # accuracy: every variant against fp32 softmax(QK^T)V on a problem small enough to materialise (incl. a ragged key count)
     for nb, n, heads, d in ((2, 1001, 8, 40), (2, 1024, 8, 80)):
@@ -70,11 +70,11 @@ def main():
         ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).transpose(1, 2).reshape(nb, n, heads * d)
         errs = []
         for x in variants:
-            ops.set_option('attn_var', x)
+            ops.set_option('attn_qb', x)
             o = ops.attention(q, k, vt, heads, d ** -0.5).float()
-            errs.append(f'var{x}: rel-L2 {float((o - ref).norm() / ref.norm()):.3e} max {float((o - ref).abs().max()):.2e}')
+            errs.append(f'qb{x}: rel-L2 {float((o - ref).norm() / ref.norm()):.3e} max {float((o - ref).abs().max()):.2e}')
         print(f'accuracy nb={nb} n={n} d={d}: ' + '  '.join(errs), flush=True)
-    ops.set_option('attn_var', 0)
+    ops.set_option('attn_qb', 0)
 
 
 if __name__ == '__main__':

@@ -15,18 +15,6 @@
 
 alignas(16) static unsigned char cpuhip_dyn_lds[160 * 1024];
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
-// v_cvt_pkrtz_f16_f32: two floats -> packed fp16, each rounded toward zero
-typedef _Float16 cpuhip_h2 __attribute__((ext_vector_type(2)));
-static inline _Float16 cpuhip_rtz_f16(float f) {
-    _Float16 h = (_Float16)f;                       // round to nearest, then step back if that moved away from zero
-    if (std::isfinite(f) && fabsf((float)h) > fabsf(f)) {
-        unsigned short b = __builtin_bit_cast(unsigned short, h);
-        --b;                                        // next representable value toward zero (same sign)
-        h = __builtin_bit_cast(_Float16, b);
-    }
-    return h;
-}
-static inline cpuhip_h2 __builtin_amdgcn_cvt_pkrtz(float a, float b) { return cpuhip_h2{cpuhip_rtz_f16(a), cpuhip_rtz_f16(b)}; }
 static inline int __all(int pred) {                      // wave vote (all 64 lanes take part, as on the hardware)
     const int lane = (int)(cpuhip::ctx.tid.x & 63);
     cpuhip::ctx.wave_slots[lane] = pred ? 1.f : 0.f;
@@ -83,7 +71,7 @@ static void report(const char* name, int rc, const std::vector<double>& want, co
 // softmax(scale Q K^T) V per (batch, head); K / V batches are shared by kv_div query batches (CFG halves, frames of a clip)
 static long g_attn_var = 0;
 namespace vsxg {
-long gemm_option(const char*) { return g_attn_var; }       // the option table lives in gemm.hip: only "attn_var" is asked here
+long gemm_option(const char*) { return g_attn_var; }       // the option table lives in gemm.hip: only "attn_qb" is asked here
 }
 
 static void run_flash(const char* name, long nb, long kv_div, long heads, long nq, long nk, long d) {
@@ -155,14 +143,11 @@ int main(int argc, char** argv) {
     if (only < 0 || only == 1) run_flash("flash d = 80, cross-attention 150 x 77, K/V shared by 2 batches", 2, 2, 2, 150, 77, 80);
     if (only < 0 || only == 2) run_flash("flash d = 160, 64 x 64", 1, 1, 1, 64, 64, 160);
     if (only < 0 || only == 3) run_flash("flash d = 64 (CLIP / VAE head), 130 x 130", 1, 1, 2, 130, 130, 64);
-    // softmax variants and the 64-queries-per-wave form (attn_var bits 0-2; bit 3: whatever the launch size)
-    g_attn_var = 3;
-    if (only < 0 || only == 11) run_flash("flash d = 40, packed fma + truncated P, 200 x 200", 1, 1, 2, 200, 200, 40);
-    g_attn_var = 4 | 8;
+    // 64 queries per wave (option attn_qb = 2: whatever the launch size)
+    g_attn_var = 2;
     if (only < 0 || only == 12) run_flash("flash d = 40, 64 queries per wave, 300 x 200 (ragged)", 1, 1, 2, 300, 200, 40);
     if (only < 0 || only == 13) run_flash("flash d = 80, 64 queries per wave, 2 batches share K/V, 260 x 77", 2, 2, 2, 260, 77, 80);
-    g_attn_var = 4 | 2 | 8;
-    if (only < 0 || only == 14) run_flash("flash d = 40, 64 queries per wave + truncated P, 256 x 128", 1, 1, 1, 256, 128, 40);
+    if (only < 0 || only == 14) run_flash("flash d = 40, 64 queries per wave, 256 x 128", 1, 1, 1, 256, 128, 40);
     g_attn_var = 0;
     if (only < 0 || only == 4) run_temporal("temporal d = 40, 8 heads, 16 x 16 frames, 3 sites, B = 2", 2, 16, 16, 3, 8, 40);
     if (only < 0 || only == 5) run_temporal("temporal d = 80, 8 heads, 16 x 16", 1, 16, 16, 2, 8, 80);

@@ -52,20 +52,17 @@ constexpr int KV_TILE = 64;
 constexpr int VSTR = 72;          // V^T LDS row: 64 keys + one 16-byte dummy slot (odd slot count)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-// VAR: softmax instruction variants, A/B-ed on the GPU through the option "attn_var" (VSX_ATTN_VAR):
-//   bit 0: scale-and-subtract of two scores as one packed fp32 FMA (v_pk_fma_f32) instead of two v_fma_f32
-//   bit 1: P is rounded to fp16 toward zero (v_cvt_pkrtz_f16_f32) instead of to nearest (v_cvt_pk_f16_f32) — only where the
-//          softmax denominator is produced by the SAME rounded P (the ones row of the V^T tile, d = 40 / 80): a truncation's
-//          relative error is uniform on an interval as wide as a rounding's, and its mean cancels between the numerator
-//          and the denominator
-//
-// QB: 32-query column blocks per wave.  The round-4 A/B (profiles/r04_attn_ab.txt) showed that halving the softmax's VALU
-// instruction count changes nothing at d = 40: the kernel streams 16 KB of K / V^T per 128 queries and 64 keys into LDS,
-// 0.0089 B per MFMA FLOP, i.e. ~8 TB/s chip-wide at its 640 TF/s — the L2 -> LDS delivery rate that also caps the GEMM
-// main loop.  With QB = 2 a wave owns 64 queries: every K and V^T fragment read from LDS feeds two
-// MFMAs, a workgroup covers 256 queries per tile, and both the bytes delivered into LDS and the LDS fragment reads per
-// FLOP halve (128 accumulator + 64 score registers: two waves per SIMD instead of four).
-template <int D, int VAR = 0, int QB = 1>
+// QB: 32-query column blocks per wave.  With QB = 2 a wave owns 64 queries: every K and V^T fragment read from LDS feeds two
+// MFMAs and a workgroup covers 256 queries per key tile, so both the bytes delivered into LDS (16 KB per tile) and the
+// LDS fragment reads per FLOP halve; 128 accumulator + 64 score registers (188 VGPRs at d = 40, 249 at d = 80): two waves
+// per SIMD instead of four.  Measured in round 4 (profiles/r04_attn_ab*.txt; N = 4096, d = 40, 32 images: 1 055 us):
+//   * removing the if-converted mask of the partial tile (100 of 200 VALU instructions per tile): 0 %;
+//   * QB = 2: -2 ... -5 % (1 038 us); with the scale-and-subtract of two scores as one v_pk_fma_f32: -4.5 % (1 008 us);
+//   * P rounded toward zero (v_cvt_pkrtz, same issue cost as v_cvt_pk: tools/ubench/valu_rate.hip): no gain, error 2.8e-4
+//     -> 3.1e-4: dropped.
+// Neither operand delivery nor the VALU instruction count is what bounds this kernel at d = 40: the time is close to
+// (MFMA issue + VALU issue) of a SIMD's waves added up, 29 % of the MFMA work being the 40 -> 48 / 40 -> 64 padding.
+template <int D, int QB = 1>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
     constexpr int DK = (D + 15) / 16;   // k-steps of the QK^T product
     constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T
@@ -264,7 +261,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
             }
             const float neg_m = -m_i[x];
             float rs = 0.f;
-            if constexpr ((VAR & 1) != 0) {
+            {   // two scores per v_pk_fma_f32
                 const vsx_f2 sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {neg_m, neg_m};
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -275,15 +272,6 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
                         s[x][kt][r] = e0;
                         s[x][kt][r + 1] = e1;
                         if (!HAS_SPARE) rs += e0 + e1;
-                    }
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[x][kt][r], p.scale_log2e, neg_m));
-                        s[x][kt][r] = e;
-                        if (!HAS_SPARE) rs += e;
                     }
             }
             if (!HAS_SPARE) {
@@ -302,17 +290,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
                 h8 pf[QB];
 #pragma unroll
                 for (int x = 0; x < QB; ++x) {
-                    if constexpr ((VAR & 2) != 0 && HAS_SPARE) {
-                        unsigned w[4];
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-                            w[jj] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(s[x][kt][8 * s2 + 2 * jj],
-                                                                                            s[x][kt][8 * s2 + 2 * jj + 1]));
-                        pf[x] = as_h8(make_uint4(w[0], w[1], w[2], w[3]));
-                    } else {
-#pragma unroll
-                        for (int jj = 0; jj < 8; ++jj) pf[x][jj] = (half_t)s[x][kt][8 * s2 + jj];
-                    }
+                    for (int jj = 0; jj < 8; ++jj) pf[x][jj] = (half_t)s[x][kt][8 * s2 + jj];
                 }
                 const int c0 = kt * 32 + 16 * s2 + 8 * hi;
 #pragma unroll
@@ -371,22 +350,19 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 }
 
 template <int D>
-int launch_attn(const AttnParams& p, long nb, hipStream_t stream, const int var = 0) {
-    dim3 grid((unsigned)(((p.nq + 127) / 128) * (long)p.heads * nb));
-    if constexpr (D == 40 || D == 80) {        // the variants exist for the head dims of the big launches only
-        // attn_var bit 2 (4): 64 queries per wave (QB = 2) where a launch still has >= 2 workgroups per CU that way
+int launch_attn(const AttnParams& p, long nb, hipStream_t stream) {
+    if constexpr (D == 40 || D == 80) {
+        // 64 queries per wave where the launch still has two workgroups per CU that way (option "attn_qb" /
+        // VSX_ATTN_QB: 0 = this rule, 1 / 2 = always that many query blocks per wave: A/B runs and tests)
         const long wg2 = ((p.nq + 255) / 256) * (long)p.heads * nb;
-        if ((var & 4) != 0 && ((wg2 >= 512 && p.nq >= 256) || (var & 8) != 0)) {       // bit 3 (8): whatever the size (tests)
-            dim3 grid2((unsigned)wg2);
-            if (var & 2) hipLaunchKernelGGL((flash_attn_kernel<D, 2, 2>), grid2, dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((flash_attn_kernel<D, 0, 2>), grid2, dim3(256), 0, stream, p);
-        } else if ((var & 3) == 1) hipLaunchKernelGGL((flash_attn_kernel<D, 1>), grid, dim3(256), 0, stream, p);
-        else if ((var & 3) == 2) hipLaunchKernelGGL((flash_attn_kernel<D, 2>), grid, dim3(256), 0, stream, p);
-        else if ((var & 3) == 3) hipLaunchKernelGGL((flash_attn_kernel<D, 3>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((flash_attn_kernel<D, 0>), grid, dim3(256), 0, stream, p);
-    } else {
-        hipLaunchKernelGGL((flash_attn_kernel<D, 0>), grid, dim3(256), 0, stream, p);
+        const long force = vsxg::gemm_option("attn_qb");
+        if (force == 2 || (force == 0 && wg2 >= 512 && p.nq >= 256)) {
+            hipLaunchKernelGGL((flash_attn_kernel<D, 2>), dim3((unsigned)wg2), dim3(256), 0, stream, p);
+            return vsx_check_launch("vsx_attention_f16");
+        }
     }
+    dim3 grid((unsigned)(((p.nq + 127) / 128) * (long)p.heads * nb));
+    hipLaunchKernelGGL((flash_attn_kernel<D, 1>), grid, dim3(256), 0, stream, p);
     return vsx_check_launch("vsx_attention_f16");
 }
 
@@ -847,9 +823,9 @@ extern "C" int vsx_attention_f16(const void* Q, const void* K, const void* VT, v
         case 8: return launch_attn<8>(p, nb, stream);
         case 16: return launch_attn<16>(p, nb, stream);
         case 32: return launch_attn<32>(p, nb, stream);
-        case 40: return launch_attn<40>(p, nb, stream, (int)vsxg::gemm_option("attn_var"));
+        case 40: return launch_attn<40>(p, nb, stream);
         case 64: return launch_attn<64>(p, nb, stream);
-        case 80: return launch_attn<80>(p, nb, stream, (int)vsxg::gemm_option("attn_var"));
+        case 80: return launch_attn<80>(p, nb, stream);
         case 128: return launch_attn<128>(p, nb, stream);
         case 160: return launch_attn<160>(p, nb, stream);
         default: return vsx_fail(VSX_E_UNSUPPORTED, "attention: head dim %ld not in {8,16,32,40,64,80,128,160}", (long)d);
