@@ -169,6 +169,28 @@ int vsx_attention_f16(const void* Q, const void* K, const void* VT, void* O, int
                       int64_t ldvt, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t vt_bs,
                       int64_t o_bs, int64_t kv_div, float scale, vsx_stream_t stream);
 
+/* Training form of K5/K6 (ABI 8; the adapter training step differentiates through every attention of the frozen UNet,
+ * trainer_videoswap.py:33-97):
+ *   vsx_attention_lse_f16: the same forward, additionally writing lse[b][h][q] (fp32, row length lse_ld >= nq) = log2 of
+ *       the softmax denominator in the scaled-score domain: P[q][k] = exp2(scale * log2(e) * q.k - lse[q]).
+ *   vsx_attention_bwd_f16: dQ (and, when dK / dV are given, dK and dV) from dO WITHOUT materialising the [heads, nq, nk]
+ *       probabilities: P is recomputed tile by tile from lse, dS = scale * P o (dO V^T - delta), delta[q] = dO[q].O[q]
+ *       (computed here into the caller's `delta` buffer), dQ = dS K, dK = dS^T Q, dV = P^T dO; two MFMA kernels, no atomics.
+ *       Q, O, dO, dQ [nb, nq, heads*d]; K, V, dK, dV [nb / kv_div, nk, heads*d]: all contiguous rows.
+ *       QT, dOT [nb, heads*d, ldtq], KT [nb / kv_div, heads*d, ldtk]: per-image transposes, rows zero-padded to a multiple
+ *       of 8 (QT / dOT only for dK / dV); lse, delta [nb, heads, lds], lds a multiple of 64, zero beyond nq.
+ *       kv_div > 1 (text K / V shared by the frames of a clip): dQ only.  d in {40, 64, 80}
+ *       (vsx_attention_bwd_supported); other head dims keep the materialised path of videoswap_amd/autograd.py. */
+int vsx_attention_lse_f16(const void* Q, const void* K, const void* VT, void* O, float* lse, int64_t lse_ld, int64_t nb,
+                          int64_t heads, int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk, int64_t ldvt,
+                          int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t vt_bs, int64_t o_bs, int64_t kv_div,
+                          float scale, vsx_stream_t stream);
+int64_t vsx_attention_bwd_supported(int64_t d);
+int vsx_attention_bwd_f16(const void* Q, const void* K, const void* V, const void* O, const void* dO, const void* QT,
+                          const void* KT, const void* dOT, const float* lse, float* delta, void* dQ, void* dK, void* dV,
+                          int64_t nb, int64_t heads, int64_t nq, int64_t nk, int64_t d, int64_t ldtq, int64_t ldtk,
+                          int64_t lds, int64_t kv_div, float scale, vsx_stream_t stream);
+
 /* K7 helper: in-place row softmax of fp16 scores S[nrows, ld] over the first ncols columns
  * (diffusers Attention.get_attention_scores softmax; probs are then handed to the
  * Prompt-to-Prompt controller, attention_register.py:70-76). */

@@ -112,6 +112,39 @@ def attention(q, k, vt, heads, scale, kv_div=1, nk=None):
     return o.permute(0, 2, 1, 3).reshape(q.shape[0], q.shape[1], C).to(H)
 
 
+def attention_bwd_supported(dh):
+    return dh in (40, 64, 80)
+
+
+def attention_lse(q, k, vt, heads, scale, kv_div=1, nk=None):
+    """contract of ops.attention_lse: (out, lse [nb, heads, round_up(nq, 64)] in the log2 domain of the scaled scores)"""
+    nk = k.shape[1] if nk is None else nk
+    qh = _heads(q.contiguous(), heads)
+    kh = _heads(k[:, :nk].contiguous(), heads).repeat_interleave(kv_div, dim=0)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    nb, nq = q.shape[:2]
+    lse = torch.zeros(nb, heads, (nq + 63) // 64 * 64)
+    lse[..., :nq] = torch.logsumexp(s, -1) * 1.4426950408889634
+    return attention(q, k, vt, heads, scale, kv_div=kv_div, nk=nk), lse
+
+
+def attention_bwd(q, k, v, out, dout, lse, heads, scale, kv_div=1, need_kv=True):
+    """contract of ops.attention_bwd: P recomputed from lse; dS = scale * P o (dP - delta); fp16 results"""
+    nb, nq, C = q.shape
+    qh, oh, gh = _heads(q, heads), _heads(out, heads), _heads(dout, heads)
+    kh = _heads(k, heads).repeat_interleave(kv_div, dim=0)
+    vh = _heads(v, heads).repeat_interleave(kv_div, dim=0)
+    p = torch.exp2((qh @ kh.transpose(-1, -2)) * (scale * 1.4426950408889634) - lse[..., :nq, None])
+    delta = (gh * oh).sum(-1, keepdim=True)
+    ds = (p * (gh @ vh.transpose(-1, -2) - delta) * scale).to(H).float()     # the kernels feed dS / P to the MFMA in fp16
+    back = (lambda t: t.permute(0, 2, 1, 3).reshape(t.shape[0], t.shape[2], C).to(H))
+    dq = back(ds @ kh)
+    if not need_kv:
+        return dq, None, None
+    assert kv_div == 1
+    return dq, back(ds.transpose(-1, -2) @ qh), back(p.to(H).float().transpose(-1, -2) @ gh)
+
+
 def temporal_attention(q, k, v, B, fq, fk, hw, heads, scale):
     C = q.shape[-1]
     d = C // heads
@@ -328,7 +361,7 @@ _NAMES = ['linear', 'linear_vt', 'conv2d', 'attention_scores', 'head_scores', 'a
           'temporal_attention', 'group_norm', 'layer_norm', 'silu', 'quick_gelu', 'axpy', 'pack_latents',
           'unpack_latents', 'cfg_ddim_step', 'masked_blend', 'adapter_scatter', 'gemm', 'set_option', 'prof_pause',
           'geglu_fwd', 'geglu_bwd', 'silu_bwd', 'group_norm_bwd', 'layer_norm_bwd', 'softmax_bwd', 'sum_pool2x2',
-          'adapter_gather']
+          'adapter_gather', 'attention_lse', 'attention_bwd', 'attention_bwd_supported']
 
 
 @contextlib.contextmanager

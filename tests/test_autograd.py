@@ -182,7 +182,11 @@ def attn_ref(q, k, v, heads, scale, kv_div=1):
     return (p @ vh).permute(0, 2, 1, 3).reshape(nb, nq, c)
 
 
-@pytest.mark.parametrize('nb,nq,nk,heads,d,kv_div', [(3, 40, 40, 4, 16, 1), (4, 24, 13, 2, 32, 2)])
+@pytest.mark.parametrize('nb,nq,nk,heads,d,kv_div', [
+    (3, 40, 40, 4, 16, 1), (4, 24, 13, 2, 32, 2),
+    # head dims of the flash backward (csrc/attention_bwd.hip): ragged query / key tiles (200 = 128 + 72, 3 key tiles + a
+    # partial one), the text K / V shared by two images (dQ only, 77 keys), d = 80, one exact tile
+    (2, 200, 200, 2, 40, 1), (4, 150, 77, 2, 40, 2), (1, 130, 130, 2, 80, 1), (1, 128, 64, 1, 64, 1)])
 def test_attention_gradient(nb, nq, nk, heads, d, kv_div):
     C = heads * d
     q0, k0, v0, g0 = rnd(nb, nq, C, seed=40), rnd(nb // kv_div, nk, C, seed=41), rnd(nb // kv_div, nk, C, seed=42), \

@@ -140,3 +140,20 @@ def test_attention_kernels_run_on_the_cpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     print(r.stdout)
     assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_attention_backward_kernels_run_on_the_cpu(tmp_path):
+    """csrc/attention_bwd.hip on the host: the dQ kernel and the dK / dV kernel of the flash-attention backward (d = 40 / 64 /
+    80, ragged query and key tiles, text K / V shared by two images) and the delta kernel, against double-precision
+    gradients of softmax(scale Q K^T) V (tools/cpu_check/check_attention_bwd.cpp)."""
+    cxx = CXX if os.path.isfile(CXX) else shutil.which('clang++')
+    src = os.path.join(ROOT, 'tools', 'cpu_check')
+    exe = str(tmp_path / 'check_attention_bwd')
+    cmd = [cxx, '-std=c++20', '-O1', '-pthread', '-I', src, '-I', os.path.join(ROOT, 'include'), '-I',
+           os.path.join(ROOT, 'videoswap_amd', 'csrc'), '-Wno-unused-function', '-Wno-unused-value', '-Wno-division-by-zero',
+           '-x', 'c++', '-o', exe, os.path.join(src, 'check_attention_bwd.cpp')]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    print(r.stdout)
+    assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -49,6 +49,41 @@ def test_unet_matches_reference_golden(setup, name):
     assert err <= 2 * e16, f'{name}: rel-L2 {err:.3e} > 2 x fp16-emulation error {e16:.3e}'
 
 
+def test_shared_cfg_prefix_equals_the_duplicated_batch(setup):
+    """Classifier-free guidance feeds the UNet the same latents twice (pipeline_videoswap.py:556).  Given as a stride-0 batch
+    view, the product computes conv_in, the first resnet and the first self-attention once; the result must match the
+    materialised `torch.cat([latents] * 2)` batch (same arithmetic per element; GroupNorm partial sums are grouped by the
+    image count, hence the small tolerance), and a controller hooked on that self-attention switches the sharing off."""
+    blob, ora, prod = setup
+    case = blob['cases']['cfg_adapter_T3_16x24']
+    x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
+    assert x.shape[0] == 2 and txt.shape[0] == 2
+    one = x[:1].contiguous()
+    dup = one.expand(2, *one.shape[1:])
+    cat = torch.cat([one, one])
+    res = [r.half().to(DEV) for r in case['residuals']]
+    assert prod._shared_cfg_prefix(dup, txt) and not prod._shared_cfg_prefix(cat, txt)
+    with torch.no_grad():
+        a = prod(dup, 481, txt, down_block_additional_residuals=list(res)).sample.float().cpu()
+        b = prod(cat, 481, txt, down_block_additional_residuals=list(res)).sample.float().cpu()
+    sync()
+    assert a.shape == b.shape and torch.isfinite(a).all()
+    assert rel_l2(a, b) < 1e-3, rel_l2(a, b)
+    assert not torch.equal(a[0], a[1]), 'the halves must differ behind the cross-attention (different text rows)'
+    # a processor that is not this package's fused one on that self-attention (a Prompt-to-Prompt hook, a foreign
+    # processor) expects both halves: the sharing must step aside
+    from videoswap_amd.attention import AttnProcessor, AttnProcessor2_0
+    attn1 = prod.down_blocks[0].attentions[0].transformer_blocks[0].attn1
+    attn1.set_processor(type('Foreign', (AttnProcessor,), {'vsx_native': False})())
+    try:
+        assert not prod._shared_cfg_prefix(dup, txt)
+        with torch.no_grad():
+            c = prod(dup, 481, txt, down_block_additional_residuals=list(res)).sample.float().cpu()
+        assert rel_l2(c, b) < 5e-3         # (another arithmetic path: the LayerNorm in front of a foreign processor is not folded)
+    finally:
+        attn1.set_processor(AttnProcessor2_0())
+
+
 def test_unet_output_object_and_determinism(setup):
     blob, ora, prod = setup
     case = blob['cases']['plain_T4_16x16']

@@ -66,6 +66,9 @@ PROTOTYPES = {
     'vsx_layernorm': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
                               c_int64, c_void_p, c_void_p]),
     'vsx_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 14 + [c_float, c_void_p]),
+    'vsx_attention_lse_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 15 + [c_float, c_void_p]),
+    'vsx_attention_bwd_supported': (c_int64, [c_int64]),
+    'vsx_attention_bwd_f16': (c_int, [c_void_p] * 13 + [c_int64] * 9 + [c_float, c_void_p]),
     'vsx_softmax_rows': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     'vsx_softmax_rows_causal': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     'vsx_temporal_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 9

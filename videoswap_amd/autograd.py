@@ -314,21 +314,37 @@ def _attention_backward(q, k, v, do, heads, scale, kv_div, need_kv):
 
 
 class _Attention(torch.autograd.Function):
+    """Fused attention.  For the head dims the flash backward exists for (40 / 64 / 80: every spatial attention of the
+    64x64 and 32x32 levels) the forward also keeps the row log-sum-exp and the output, and the backward recomputes the
+    probabilities tile by tile (csrc/attention_bwd.hip); the other head dims (d = 160: 256 keys) keep the materialised
+    path below."""
+
     @staticmethod
     def forward(ctx, q, k, vt, heads, scale, kv_div, nk):
+        nk_eff = k.shape[1] if nk is None else nk
+        flash = 'attention_lse' in ops._raw and _k('attention_bwd_supported')(q.shape[-1] // heads)
+        ctx.cfg = (heads, scale, kv_div, nk_eff, flash)
+        if flash:
+            out, lse = _k('attention_lse')(q, k, vt, heads, scale, kv_div=kv_div, nk=nk)
+            ctx.save_for_backward(q, k, vt, out, lse)
+            return out
         out = _k('attention')(q, k, vt, heads, scale, kv_div=kv_div, nk=nk)
-        ctx.cfg = (heads, scale, kv_div, k.shape[1] if nk is None else nk)
         ctx.save_for_backward(q, k, vt)
         return out
 
     @staticmethod
     def backward(ctx, do):
-        q, k, vt = ctx.saved_tensors
-        heads, scale, kv_div, nk = ctx.cfg
+        heads, scale, kv_div, nk, flash = ctx.cfg
         need_kv = _need(ctx, 1) or _need(ctx, 2)
+        q, k, vt = ctx.saved_tensors[:3]
         kc = k[:, :nk].contiguous()
         v = vt[:, :, :nk].transpose(1, 2).contiguous()
-        dq, dk, dv = _attention_backward(q.contiguous(), kc, v, do.contiguous(), heads, scale, kv_div, need_kv)
+        if flash:
+            out, lse = ctx.saved_tensors[3:]
+            dq, dk, dv = _k('attention_bwd')(q.contiguous(), kc, v, out, do.contiguous(), lse, heads, scale, kv_div=kv_div,
+                                             need_kv=need_kv)
+        else:
+            dq, dk, dv = _attention_backward(q.contiguous(), kc, v, do.contiguous(), heads, scale, kv_div, need_kv)
         dk_full = dvt = None
         if need_kv:
             dk_full = dk if nk == k.shape[1] else torch.nn.functional.pad(dk, (0, 0, 0, k.shape[1] - nk))

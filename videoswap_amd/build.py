@@ -27,7 +27,8 @@ LIB = os.path.join(LIBDIR, 'libvsx.so')
 VARIANTS = {}
 # variant name -> additional sources (relative to csrc/)
 VARIANT_EXTRA = {}
-SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'elementwise.hip', 'train.hip']
+SOURCES = ['api.cpp', 'comm.cpp', 'gemm.hip', 'gemm_pp.hip', 'norm.hip', 'attention.hip', 'attention_bwd.hip', 'elementwise.hip',
+           'train.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip',
          '-I', os.path.join(ROOT, 'include'), '-I', CSRC, '-Wall', '-Wno-unused-function', '-Wno-division-by-zero',

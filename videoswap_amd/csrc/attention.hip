@@ -38,6 +38,8 @@ struct AttnParams {
     long q_bs, k_bs, vt_bs, o_bs;
     int kv_div;
     float scale_log2e;
+    float* lse;     // optional [nb, heads, lse_ld]: log2 of the softmax denominator in the scaled-score domain (training)
+    long lse_ld;
 };
 
 // -DVSX_GEMM_TIMING (tools/gemm_timing.py): per-wave cycle totals of the key-loop segments, long[block][wave][6]
@@ -331,6 +333,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         // ---- normalise and store: lane (q, hi) holds O[q, t*32 + 8*g + 4*hi + 0..3] ----
         const int q = q0 + 32 * x;
         if (q < p.nq) {
+            // what the backward pass recomputes P from: P = exp2(s * scale * log2(e) - lse)
+            if (p.lse && hi == 0) p.lse[(b * p.heads + h) * p.lse_ld + q] = m_i[x] + __log2f(l_i[x]);
             const float inv = 1.0f / l_i[x];
             half_t* orow = p.O + b * p.o_bs + (long)q * p.ldo + h * D;
 #pragma unroll
@@ -795,10 +799,30 @@ extern "C" int vsx_attn_debug_buffer(void* buf) {
 }
 #endif
 
+static int attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* lse, int64_t lse_ld, int64_t nb, int64_t heads,
+                         int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t q_bs,
+                         int64_t k_bs, int64_t vt_bs, int64_t o_bs, int64_t kv_div, float scale, vsx_stream_t stream_);
+
 extern "C" int vsx_attention_f16(const void* Q, const void* K, const void* VT, void* O, int64_t nb, int64_t heads,
                                  int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk, int64_t ldvt,
                                  int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t vt_bs, int64_t o_bs,
-                                 int64_t kv_div, float scale, vsx_stream_t stream_) {
+                                 int64_t kv_div, float scale, vsx_stream_t stream) {
+    return attention_fwd(Q, K, VT, O, nullptr, 0, nb, heads, nq, nk, d, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, kv_div, scale,
+                         stream);
+}
+
+extern "C" int vsx_attention_lse_f16(const void* Q, const void* K, const void* VT, void* O, float* lse, int64_t lse_ld,
+                                     int64_t nb, int64_t heads, int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk,
+                                     int64_t ldvt, int64_t ldo, int64_t q_bs, int64_t k_bs, int64_t vt_bs, int64_t o_bs,
+                                     int64_t kv_div, float scale, vsx_stream_t stream) {
+    VSX_REQUIRE(lse != nullptr && lse_ld >= nq, VSX_E_BADSHAPE, "attention_lse: lse buffer / row length");
+    return attention_fwd(Q, K, VT, O, lse, lse_ld, nb, heads, nq, nk, d, ldq, ldk, ldvt, ldo, q_bs, k_bs, vt_bs, o_bs, kv_div, scale,
+                         stream);
+}
+
+static int attention_fwd(const void* Q, const void* K, const void* VT, void* O, float* lse, int64_t lse_ld, int64_t nb, int64_t heads,
+                         int64_t nq, int64_t nk, int64_t d, int64_t ldq, int64_t ldk, int64_t ldvt, int64_t ldo, int64_t q_bs,
+                         int64_t k_bs, int64_t vt_bs, int64_t o_bs, int64_t kv_div, float scale, vsx_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     VSX_REQUIRE(Q && K && VT && O, VSX_E_BADSHAPE, "attention: null tensor");
     if (nb == 0 || nq == 0) return VSX_OK;
@@ -819,6 +843,8 @@ extern "C" int vsx_attention_f16(const void* Q, const void* K, const void* VT, v
     p.q_bs = q_bs; p.k_bs = k_bs; p.vt_bs = vt_bs; p.o_bs = o_bs;
     p.kv_div = (int)kv_div;
     p.scale_log2e = scale * 1.44269504088896340736f;
+    p.lse = lse;
+    p.lse_ld = lse_ld;
     switch (d) {
         case 8: return launch_attn<8>(p, nb, stream);
         case 16: return launch_attn<16>(p, nb, stream);

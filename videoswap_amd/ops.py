@@ -740,6 +740,66 @@ def softmax_bwd(probs, dprobs, scale):
     return dprobs
 
 
+def attention_bwd_supported(dh):
+    """Head dims the flash-attention backward kernels exist for (csrc/attention_bwd.hip)."""
+    return bool(_train_fn('vsx_attention_bwd_supported')(int(dh)))
+
+
+def attention_lse(q, k, vt, heads, scale, kv_div=1, nk=None):
+    """`attention` that also returns lse [nb, heads, round_up(nq, 64)] fp32 (log2 of the softmax denominators in the
+    scaled-score domain, zero beyond nq): what `attention_bwd` recomputes the probabilities from."""
+    _chk(vt, 'vt')
+    ldq, q_bs = _rows_view(q, 'q')
+    ldk, k_bs = _rows_view(k, 'k')
+    nb, nq, C = q.shape
+    nk = k.shape[1] if nk is None else nk
+    dh = C // heads
+    out = torch.empty(nb, nq, C, dtype=_F16, device=q.device)
+    lds = round_up(nq, 64)
+    lse = torch.zeros(nb, heads, lds, dtype=torch.float32, device=q.device)
+    if FlopCounter.enabled:
+        FlopCounter.attention += 4.0 * nb * heads * nq * nk * dh
+    check(_train_fn('vsx_attention_lse_f16')(_p(q), _p(k), _p(vt), _p(out), _p(lse), lds, nb, heads, nq, nk, dh, ldq, ldk,
+                                             vt.shape[2], C, q_bs, k_bs, C * vt.shape[2], nq * C, kv_div, float(scale),
+                                             _stream()), 'vsx_attention_lse_f16')
+    return out, lse
+
+
+def attention_bwd(q, k, v, out, dout, lse, heads, scale, kv_div=1, need_kv=True):
+    """Data gradients of the fused attention without the [heads, nq, nk] probabilities (csrc/attention_bwd.hip).
+    q, out, dout [nb, nq, C]; k, v [nb / kv_div, nk, C], all contiguous; lse from `attention_lse`.
+    -> (dq, dk, dv) (dk = dv = None unless need_kv; kv_div > 1: dq only)."""
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v'), (out, 'out'), (dout, 'dout')):
+        _chk(t, n)
+    _chk(lse, 'lse', torch.float32)
+    nb, nq, C = q.shape
+    nk = k.shape[1]
+    dh = C // heads
+    lds = lse.shape[-1]
+
+    def transposed(t):          # [n_img, n, C] -> [n_img, C, round_up(n, 8)], zero padded
+        n = t.shape[1]
+        ld = round_up(n, 8)
+        tt = torch.zeros(t.shape[0], C, ld, dtype=_F16, device=t.device) if ld != n else \
+            torch.empty(t.shape[0], C, ld, dtype=_F16, device=t.device)
+        tt[:, :, :n] = t.transpose(1, 2)
+        return tt
+    kt = transposed(k)
+    qt = dot = dk = dv = None
+    if need_kv:
+        if kv_div != 1:
+            raise _lib.VsxError('attention_bwd: key / value gradients of a shared (text) context')
+        qt, dot = transposed(q), transposed(dout)
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+    dq = torch.empty_like(q)
+    delta = torch.empty(nb, heads, lds, dtype=torch.float32, device=q.device)
+    check(_train_fn('vsx_attention_bwd_f16')(_p(q), _p(k), _p(v), _p(out), _p(dout), _p(qt), _p(kt), _p(dot), _p(lse),
+                                             _p(delta), _p(dq), _p(dk), _p(dv), nb, heads, nq, nk, dh,
+                                             qt.shape[2] if qt is not None else 0, kt.shape[2], lds, kv_div, float(scale),
+                                             _stream()), 'vsx_attention_bwd_f16')
+    return dq, dk, dv
+
+
 def sum_pool2x2(x):
     """[n, 2h, 2w, c] -> [n, h, w, c]: the data gradient of the nearest-2x upsampling folded into a conv's loader."""
     _chk(x, 'x')
@@ -783,7 +843,8 @@ _ACTIVATIONS = {
     'adapter_scatter': ((2,), ()),
 }
 _PLAIN = ('gemm', 'set_option', 'prof_pause', 'prof_enable', 'prof_collect', 'geglu_fwd', 'geglu_bwd', 'silu_bwd',
-          'group_norm_bwd', 'layer_norm_bwd', 'softmax_bwd', 'sum_pool2x2', 'adapter_gather')
+          'group_norm_bwd', 'layer_norm_bwd', 'softmax_bwd', 'sum_pool2x2', 'adapter_gather', 'attention_lse',
+          'attention_bwd', 'attention_bwd_supported')
 
 
 def _publish(name):

@@ -280,7 +280,12 @@ class VideoSwapPipeline:
 
         n = len(timesteps)
         for i, t in enumerate(timesteps):
-            model_input = torch.cat([latents] * 2) if do_cfg else latents
+            # both CFG halves see the same latents (pipeline_videoswap.py:556).  For one clip the duplicate is a stride-0 view:
+            # the UNet then knows the halves are identical up to the first cross-attention and computes that prefix once
+            if do_cfg and latents.shape[0] == 1:
+                model_input = latents.expand(2, *latents.shape[1:])
+            else:
+                model_input = torch.cat([latents] * 2) if do_cfg else latents
             if adapter_state is not None and n * t2i_start <= i <= n * t2i_end:
                 t2i_residual = list(adapter_state)      # fresh list: the UNet pops from it
             else:

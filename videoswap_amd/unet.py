@@ -140,9 +140,12 @@ class BasicTransformerBlock(nn.Module):
             text = text.repeat_interleave(frames, dim=0)
         return ops.axpy(attn(normed, encoder_hidden_states=text), x)
 
-    def forward(self, x, encoder_hidden_states=None, timestep=None, attention_mask=None, video_length=None):
+    def forward(self, x, encoder_hidden_states=None, timestep=None, attention_mask=None, video_length=None,
+                split_after_self=False):
         # the LayerNorms are folded into the projections that consume them when the processor is one of this package's
         x = self._attend(self.attn1, self.norm1(x, defer=_native(self.attn1)), x, None, video_length)
+        if split_after_self:        # shared CFG prefix (AnimateDiffUNet3DModel._forward_body): the text makes the halves differ
+            x = torch.cat([x, x])
         x = self._attend(self.attn2, self.norm2(x, defer=_native(self.attn2)), x, encoder_hidden_states, video_length)
         return self.ff(self.norm3(x, defer=True), residual=x)
 
@@ -169,12 +172,18 @@ class Transformer3DModel(nn.Module):
                                   cross_attention_dim=cross_attention_dim)])
         self.proj_out = PointwiseConv(inner, in_channels, kernel_size=1)
 
-    def forward(self, x, geo, encoder_hidden_states=None):
+    def forward(self, x, geo, encoder_hidden_states=None, split_after_self=False):
+        """`split_after_self`: x holds ONE copy of a classifier-free-guidance batch whose halves are identical so far; the
+        result holds both halves (they part at the cross-attention)."""
         bf, h, w, c = x.shape
         y = self.norm(x, bf)
         y = self.proj_in(y.view(bf, h * w, c))
         for block in self.transformer_blocks:
-            y = block(y, encoder_hidden_states=encoder_hidden_states, video_length=geo.F)
+            y = block(y, encoder_hidden_states=encoder_hidden_states, video_length=geo.F,
+                      split_after_self=split_after_self)
+        if split_after_self:
+            x = torch.cat([x, x])
+            bf *= 2
         y = self.proj_out(y, residual=x.view(bf, h * w, c))
         return y.view(bf, h, w, c)
 
@@ -323,12 +332,18 @@ class CrossAttnDownBlock3D(nn.Module):
         self.downsamplers = nn.ModuleList([Downsample3D(out_channels, out_channels=out_channels)]) \
             if add_downsample else None
 
-    def forward(self, x, silu_temb, geo, encoder_hidden_states=None, additional_residuals=None):
+    def forward(self, x, silu_temb, geo, encoder_hidden_states=None, additional_residuals=None, shared_geo=None):
+        """`shared_geo` (first down block only): x is the single copy of two identical CFG halves, with its geometry; the
+        first resnet and the first self-attention run once, the halves part at that transformer's cross-attention."""
         outs = ()
         last = len(self.resnets) - 1
         for i, (res, attn, mm) in enumerate(zip(self.resnets, self.attentions, self.motion_modules)):
-            x = res(x, silu_temb, geo)
-            x = attn(x, geo, encoder_hidden_states=encoder_hidden_states)
+            if i == 0 and shared_geo is not None:
+                x = res(x, silu_temb, shared_geo)
+                x = attn(x, shared_geo, encoder_hidden_states=encoder_hidden_states, split_after_self=True)
+            else:
+                x = res(x, silu_temb, geo)
+                x = attn(x, geo, encoder_hidden_states=encoder_hidden_states)
             if mm is not None:
                 x = mm(x, geo)
             if i == last and additional_residuals is not None:     # unet_blocks.py:399-402
@@ -637,7 +652,16 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         geo = Geometry(B, F, None if shard is None else shard.gn_hook, None if shard is None else shard.total_frames,
                        shard if shard is not None and shard.exchange != 'kv' else None)
 
-        x = ops.pack_latents(sample.contiguous(), 8)            # [B*F, H, W, 8] (latent channels zero-padded)
+        # Classifier-free guidance hands the UNet the SAME latents twice (pipeline_videoswap.py:556: `torch.cat([latents] * 2)`);
+        # the halves only part at the first cross-attention.  When the caller proves the duplication by passing a
+        # stride-0 batch view (`latents.expand(2, ...)`: VideoSwapPipeline does), conv_in, the first resnet and the first
+        # self-attention (N = H*W keys: the largest attention launch of the model) run once for both halves.
+        shared_geo = None
+        if self._shared_cfg_prefix(sample, encoder_hidden_states):
+            shared_geo = Geometry(1, F)
+            x = ops.pack_latents(sample[:1].contiguous(), 8)
+        else:
+            x = ops.pack_latents(sample.contiguous(), 8)        # [B*F, H, W, 8] (latent channels zero-padded)
         x = self.conv_in(x)
 
         is_adapter = residuals is not None
@@ -646,12 +670,15 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         def pop_residual():
             return residuals.pop(0)
 
-        skips = (x,)
+        skips = (x if shared_geo is None else torch.cat([x, x]),)
         for blk in self.down_blocks:
             if blk.has_cross_attention:
                 extra = pop_residual() if (is_adapter and len(residuals) > 0) else None
+                kw = {}
+                if shared_geo is not None:
+                    kw['shared_geo'], shared_geo = shared_geo, None
                 x, outs = blk(x, silu_emb, geo, encoder_hidden_states=encoder_hidden_states,
-                              additional_residuals=extra)
+                              additional_residuals=extra, **kw)
             else:
                 x, outs = blk(x, silu_emb, geo, encoder_hidden_states=encoder_hidden_states)
                 if is_adapter and len(residuals) > 0:           # unet.py:434-438: after the skips are taken
@@ -697,6 +724,21 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
     def _apply(self, fn, *args, **kwargs):
         self._weights_epoch = getattr(self, '_weights_epoch', 0) + 1
         return super()._apply(fn, *args, **kwargs)
+
+    def _shared_cfg_prefix(self, sample, text):
+        """Can the two batch items share everything in front of the first cross-attention?  Only when the caller PROVES
+        that they are identical (a stride-0 batch dimension), the first block is a cross-attention block whose first
+        self-attention runs on this package's fused processor (a controller hooked there expects both halves), and the
+        clip is not frame-sharded."""
+        if sample.shape[0] != 2 or sample.stride(0) != 0 or self._frame_shard is not None:
+            return False
+        if text is None or text.shape[0] != 2 or os.environ.get('VSX_CFG_SHARED_PREFIX', '1') == '0':
+            return False
+        blk = self.down_blocks[0]
+        if not getattr(blk, 'has_cross_attention', False) or len(blk.attentions) == 0:
+            return False
+        tb = blk.attentions[0].transformer_blocks[0]
+        return _native(tb.attn1) and _native(tb.attn2)
 
     def _graphable(self, sample, silu_emb, text):
         if self._frame_shard is not None or not sample.is_cuda or silu_emb.shape[0] != 1:
