@@ -466,6 +466,35 @@ def test_attention_query_blocks_per_wave(qb, nb, heads, nq, nk, d, kv_div):
     assert torch.equal(out, other), 'a query\'s result must not depend on how many query blocks its wave owns'
 
 
+@pytest.mark.parametrize('nb,heads,nq,nk,d,kv_div', [(2, 8, 1024, 1024, 40, 1), (2, 8, 1100, 1100, 40, 1), (4, 8, 1024, 77, 40, 2),
+                                                     (2, 8, 400, 400, 80, 1), (1, 2, 256, 256, 64, 1)])
+def test_attention_backward_flash(nb, heads, nq, nk, d, kv_div):
+    """vsx_attention_lse_f16 + vsx_attention_bwd_f16 (csrc/attention_bwd.hip) against PyTorch autograd of the fp32
+    softmax(scale Q K^T) V on the same fp16 inputs: output, log-sum-exp, dQ, dK, dV (shared text K / V: dQ only); ragged
+    query / key tiles (1100 = 8 x 128 + 76)."""
+    C = heads * d
+    q, k, v = rnd(nb, nq, C, seed=141), rnd(nb // kv_div, nk, C, seed=142), rnd(nb // kv_div, nk, C, seed=143)
+    g = rnd(nb, nq, C, seed=144)
+    scale = d ** -0.5
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref, _ = attn_ref(qr, kr, vr, heads, scale, kv_div=kv_div)
+    (ref * g.float()).sum().backward()
+    out, lse = ops().attention_lse(q, k, make_vt(v), heads, scale, kv_div=kv_div)
+    assert rel_err(out, ref.detach(), l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
+    qh = q.float().view(nb, nq, heads, d).transpose(1, 2)
+    kh = k.float().view(nb // kv_div, nk, heads, d).transpose(1, 2).repeat_interleave(kv_div, 0)
+    want_lse = torch.logsumexp(qh @ kh.transpose(-1, -2) * scale, -1) * 1.4426950408889634
+    assert (lse[..., :nq] - want_lse).abs().max() < 2e-2 and float(lse[..., nq:].abs().sum()) == 0.0
+    self_attn = kv_div == 1
+    dq, dk, dv = ops().attention_bwd(q, k, v, out, g, lse, heads, scale, kv_div=kv_div, need_kv=self_attn)
+    assert rel_err(dq, qr.grad, l2_tol=4e-3, row_tol=2e-2) < 8e-3
+    if self_attn:
+        assert rel_err(dk, kr.grad, l2_tol=4e-3, row_tol=2e-2) < 8e-3
+        assert rel_err(dv, vr.grad, l2_tol=4e-3, row_tol=2e-2) < 8e-3
+    else:
+        assert dk is None and dv is None
+
+
 def test_attention_self_benchmark_shape():
     """N = 4096, d = 40, 8 heads: the 64x64-level self-attention of the benchmarked model (32 query tiles per head,
     XCD-ordered workgroups); nb = 4 keeps the fp32 reference's score tensor at 2 GiB."""
