@@ -40,12 +40,13 @@ def _derived(weight, kind, fn):
         import weakref
         with torch.no_grad():
             val = fn(weight.detach())
+        fresh = hit is None or hit[1]() is not weight
         try:
             ref = weakref.ref(weight)
+            if fresh:                           # the entry lives as long as the tensor object it was derived from
+                weakref.finalize(weight, _wcache.pop, key, None)
         except TypeError:  # pragma: no cover
             ref = (lambda w=weight: w)
-        if len(_wcache) > 4096:
-            _wcache.clear()
         hit = (stamp, ref, val)
         _wcache[key] = hit
     return hit[2]

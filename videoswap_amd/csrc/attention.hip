@@ -59,7 +59,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // LDS fragment reads per FLOP halve; 128 accumulator + 64 score registers (188 VGPRs at d = 40, 249 at d = 80): two waves
 // per SIMD instead of four.  Measured in round 4 (profiles/r04_attn_ab*.txt; N = 4096, d = 40, 32 images: 1 055 us):
 //   * removing the if-converted mask of the partial tile (100 of 200 VALU instructions per tile): 0 %;
-//   * QB = 2: -2 ... -5 % (1 038 us); with the scale-and-subtract of two scores as one v_pk_fma_f32: -4.5 % (1 008 us);
+//   * QB = 2: -2 ... -5 % on one box (1 038 us; with the scale-and-subtract of two scores as one v_pk_fma_f32 1 008 us),
+//     +3 % on another; d = 80 (N = 1024): -4 ... -5 % on both -> the launch rule takes QB = 2 for d = 80 only;
 //   * P rounded toward zero (v_cvt_pkrtz, same issue cost as v_cvt_pk: tools/ubench/valu_rate.hip): no gain, error 2.8e-4
 //     -> 3.1e-4: dropped.
 // Neither operand delivery nor the VALU instruction count is what bounds this kernel at d = 40: the time is close to
@@ -356,11 +357,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
 template <int D>
 int launch_attn(const AttnParams& p, long nb, hipStream_t stream) {
     if constexpr (D == 40 || D == 80) {
-        // 64 queries per wave where the launch still has two workgroups per CU that way (option "attn_qb" /
-        // VSX_ATTN_QB: 0 = this rule, 1 / 2 = always that many query blocks per wave: A/B runs and tests)
+        // 64 queries per wave (option "attn_qb" / VSX_ATTN_QB: 0 = the rule below, 1 / 2 = always that many query blocks
+        // per wave: A/B runs and tests).  Three boxes, interleaved rounds (profiles/r04_attn_ab*.txt): d = 80 gains 4 - 5 %
+        // every time; d = 40 moves between - 3 % and + 5 % with the box and the image count (four waves per SIMD hide
+        // more than two), so it keeps 32 queries per wave.
         const long wg2 = ((p.nq + 255) / 256) * (long)p.heads * nb;
         const long force = vsxg::gemm_option("attn_qb");
-        if (force == 2 || (force == 0 && wg2 >= 512 && p.nq >= 256)) {
+        if (force == 2 || (force == 0 && D == 80 && wg2 >= 512 && p.nq >= 256)) {
             hipLaunchKernelGGL((flash_attn_kernel<D, 2>), dim3((unsigned)wg2), dim3(256), 0, stream, p);
             return vsx_check_launch("vsx_attention_f16");
         }

@@ -105,7 +105,14 @@ class InflatedConv3d(nn.Conv2d):
     def ohwi(self, cin_pad=0):
         w = self.weight
         if not cin_pad and w.is_contiguous(memory_format=torch.channels_last):
-            return w.detach().permute(0, 2, 3, 1)      # zero-copy view, contiguous as [O, kh, kw, I]
+            # zero-copy view, contiguous as [O, kh, kw, I].  The SAME view object is handed out while the parameter's storage
+            # stays in place: caches keyed on the tensor object (the flipped dgrad copies of videoswap_amd/autograd.py) would
+            # otherwise miss on every call — the round-3 training step rebuilt ~1 GB of them per step and kept the old ones
+            key = (w.data_ptr(), w.dtype, w.device)
+            hit = self.__dict__.get('_ohwi_view')
+            if hit is None or hit[0] != key:
+                hit = self.__dict__['_ohwi_view'] = (key, w.detach().permute(0, 2, 3, 1))
+            return hit[1]
         return self._packed.get(w, cin_pad)
 
     def forward(self, x, x2=None, upsample=False, rowvec=None, rows_per_vec=0, residual=None):
