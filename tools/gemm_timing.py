@@ -110,5 +110,60 @@ def run_attn(nb, heads, nq, nk, d):
         print(f'    {n:28s} {x:8.0f} cyc  {100 * x / tot:5.1f}%')
 
 
+def run_pp():
+    """Persistent GEMM: cycles a workgroup spends in its K loops / its epilogues / the barrier behind them, per tile, for
+    the shapes that carry the UNet's GEMM time (B = 2, T = 16, 64x64 and 32x32 levels)."""
+    import torch
+    from videoswap_amd import _lib, ops
+    _lib.LIB_PATH = LIB
+    lib = _lib.load()
+    lib.vsx_pp_debug_buffer.restype = ctypes.c_int
+    lib.vsx_pp_debug_buffer.argtypes = [ctypes.c_void_p]
+    dbg = torch.zeros(256 * 8 * 4, dtype=torch.int64, device='cuda')
+    assert lib.vsx_pp_debug_buffer(ctypes.c_void_p(dbg.data_ptr())) == 0
+    dev, h16 = 'cuda', torch.float16
+
+    def r(*s, scale=1.0):
+        return (torch.randn(*s, device=dev) * scale).to(h16)
+    cases = []
+    for M, K, N, kind in ((131072, 320, 1280, 'geglu'), (131072, 320, 320, 'res'), (131072, 320, 960, 'plain'),
+                          (131072, 1280, 320, 'res'), (32768, 640, 2560, 'geglu'), (32768, 640, 640, 'res'),
+                          (32768, 2560, 640, 'res'), (8192, 1280, 5120, 'geglu')):
+        x = r(M, K)
+        if kind == 'geglu':
+            w, b = r(2 * N, K, scale=K ** -0.5), r(2 * N)
+            cases.append((f'geglu M={M} {K}->{N}', (lambda x=x, w=w, b=b: ops.linear(x, w, b, geglu=True)), 2.0 * M * 2 * N * K))
+        else:
+            w, b = r(N, K, scale=K ** -0.5), r(N)
+            res = r(M, N) if kind == 'res' else None
+            cases.append((f'gemm M={M} {K}->{N}' + (' +res' if res is not None else ''),
+                          (lambda x=x, w=w, b=b, res=res: ops.linear(x, w, b, residual=res)), 2.0 * M * N * K))
+    xc = r(32, 64, 64, 320)
+    wc, bc = r(320, 3, 3, 320, scale=(9 * 320) ** -0.5), r(320)
+    cases.append(('conv3x3 64x64 320->320', (lambda: ops.conv2d(xc, wc, bc)), 2.0 * 32 * 4096 * 320 * 9 * 320))
+    print('shape                               us    TF/s   tiles/WG   cycles per tile: K loop   epilogue   barrier    epilogue share')
+    for name, fn, flop in cases:
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        dbg.zero_()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b_.record(); b_.synchronize()
+        us = a.elapsed_time(b_) * 1e3
+        t = dbg.view(256, 8, 4).double()
+        live = t[:, :, 3] > 0
+        if not bool(live.any()):
+            print(f'{name:32s} {us:7.1f}  (not on the persistent kernel)')
+            continue
+        tiles = t[:, :, 3][live].mean().item()
+        per = [(t[:, :, i][live] / t[:, :, 3][live]).mean().item() for i in range(3)]
+        print(f'{name:32s} {us:7.1f} {flop / us / 1e6:7.0f} {tiles:9.1f} {per[0]:24.0f} {per[1]:10.0f} {per[2]:9.0f} '
+              f'{per[1] / sum(per):16.2f}')
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'pp':
+    run_pp()
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'attn':
     run_attn(*[int(x) for x in sys.argv[2:7]])

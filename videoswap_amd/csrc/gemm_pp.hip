@@ -40,6 +40,11 @@
 #include <stdlib.h>
 
 namespace vsxg {
+#ifdef VSX_GEMM_TIMING
+// -DVSX_GEMM_TIMING (tools/gemm_timing.py pp ...): per-wave cycle totals long[workgroup][wave][4] = main loop (all K slabs of
+// all tiles), epilogue, barrier after the epilogue, tiles
+__device__ long* g_pp_dbg = nullptr;
+#endif
 namespace {
 
 typedef const __attribute__((address_space(4))) GemmParams* kparams_t;
@@ -622,6 +627,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     if (G == 1) bar();                          // group 1 runs one phase behind
 
     int c_g = 0;
+#ifdef VSX_GEMM_TIMING
+    long t_seg[3] = {0, 0, 0}, t_last = (long)__builtin_amdgcn_s_memtime();
+#define PPSTAMP(i) do { const long t_now = (long)__builtin_amdgcn_s_memtime(); t_seg[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define PPSTAMP(i) do { } while (0)
+#endif
     for (int c_t = 0; c_t < n_my; ++c_t) {
         for (int kt = 0; kt < nk; ++kt, ++c_g) {
             const int so = (c_g & 1) * STAGE;
@@ -675,6 +686,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         // 0..NFIT-1) and the LDS behind the ring (the others), and G0's next load phase issues DMA into that slot —
         // and G1 drops one phase behind again.  (The other slot holds slab 0 of the next tile, already landed.) ----
         if (G == 0) bar();
+        PPSTAMP(0);
         {
             const int tile = tile0 + c_t * wgx;
             int tile_n, tile_m;
@@ -688,9 +700,17 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         }
         __builtin_amdgcn_sched_barrier(0);
         lgkm0();
+        PPSTAMP(1);
         bar();
         if (G == 1) bar();
+        PPSTAMP(2);
     }
+#ifdef VSX_GEMM_TIMING
+    if (lane == 0 && g_pp_dbg) {
+        long* o_dbg = g_pp_dbg + ((long)blockIdx.x * 8 + wave) * 4;
+        o_dbg[0] = t_seg[0]; o_dbg[1] = t_seg[1]; o_dbg[2] = t_seg[2]; o_dbg[3] = n_my;
+    }
+#endif
     if (G == 0) bar();                          // matches group 1's extra barrier at the start
 }
 
@@ -720,6 +740,12 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef VSX_GEMM_TIMING
+extern "C" int vsx_pp_debug_buffer(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pp_dbg), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 bool pp_supported(const GemmParams& p) {
     // no column edge (N a multiple of the tile), 16-byte epilogue accesses, fast-tap convolutions, 32-bit offsets
