@@ -262,17 +262,24 @@ def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched, adden
     Wo = (2 * W if ups else W) // stride
     rowvec = rnd(nimg, Cout, seed=101) if addend == 'rowvec' else None
     res = rnd(nimg, Ho, Wo, Cout, seed=102) if addend == 'residual' else None
+    run = (lambda: ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec,
+                                rows_per_vec=Ho * Wo if rowvec is not None else 0, residual=res))
+    # pp_sched bit 4: the tap-major K order, which sums like the tile kernels (bit for bit); the default order (the taps of a
+    # 64-channel slab back to back: one fabric read of the input window instead of one per tap) is another fp32 summation order
+    ops().set_option('pp_sched', _sched(sched) | 4)
+    old, same_order = both_gemm_paths(run)
     ops().set_option('pp_sched', _sched(sched))
-    old, new = both_gemm_paths(lambda: ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec,
-                                                    rows_per_vec=Ho * Wo if rowvec is not None else 0, residual=res))
+    _, new = both_gemm_paths(run)
     ref = conv_ref(x, w, b, stride, x2, ups)
     if rowvec is not None:
         ref = ref + rowvec.float()[:, None, None, :]
     if res is not None:
         ref = ref + res.float()
     assert rel_err(new, ref) < 2e-3
+    assert rel_err(same_order, ref) < 2e-3
+    assert rel_err(new, same_order.float(), l2_tol=1e-4, row_tol=1e-3) < 2e-3      # two summation orders of the same products
     if nimg * Ho * Wo >= 8192:       # (smaller problems take split-K on the tile-kernel side: other summation order)
-        assert torch.equal(old, new)
+        assert torch.equal(old, same_order)
     else:
         assert rel_err(old, ref) < 2e-3
 

@@ -46,7 +46,7 @@ static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
 struct Case { const char* name; long M, N, K; bool res, geglu; int bm; bool ln = false; };
 
 static int n_bad = 0;
-static std::vector<long> g_scheds = {0, 8, 4, 12};      // pp_sched bits: 8 = linear tile walk instead of the 2-D one; 4 = conv K order (taps inner)
+static std::vector<long> g_scheds = {0, 8, 4, 12};      // pp_sched bits: 8 = linear tile walk instead of the 2-D one; 4 = conv K order tap-major (default: taps of a channel slab back to back)
 
 static std::vector<half_t> pack_b(const std::vector<half_t>& w, long rows, long K) {      // [N/8][K/64][8][64]
     std::vector<half_t> out(w.size());
@@ -169,7 +169,7 @@ static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, i
                         }
                     want[((size_t)(i * Ho + ho) * Wo + wo) * Cout + co] = s;
                 }
-    std::vector<half_t> firsts[2];              // per K order (pp_sched & 4: taps of a channel slab back to back): another fp32 summation order
+    std::vector<half_t> firsts[2];              // per K order (pp_sched & 4: tap-major instead of taps-inner): another fp32 summation order
     for (long sched : g_scheds) {
         std::vector<half_t>& first = firsts[(sched >> 2) & 1];
         std::vector<half_t> C((size_t)M * Cout, (half_t)-7.f);

@@ -37,14 +37,22 @@ struct GemmParams {
 // pp_flags: option bits of "pp_sched" / VSX_PP_SCHED.  Round 3 measured five candidates on the GPU
 // (profiles/r03_gemm_option_ab*_b2.txt, r03_gemm_sched_ab_b2.txt) and kept one: the 2-D tile walk inside an XCD is the
 // default (same speed, 2.5x less HBM traffic on the wide-N GEMMs); 8 restores the linear walk for A/B runs.  Dropped:
-// other cut points of the DMA piece schedule (+-1 %), conv slab order "taps of a channel slab back to back" (8-13 %
-// slower: the per-slab address update runs on the VALU, which is blocked while the partner wave streams MFMAs), no
+// other cut points of the DMA piece schedule (+-1 %), conv slab order "taps of a channel slab back to back" with a full
+// address recomputation per slab (8-13 % slower; round 4's loader keeps three VALU operations per piece and slab and made
+// that order the default, PP_CONV_TAP_MAJOR below), no
 // s_setprio / s_setprio on the LOAD phase (+-1 %), K-start stagger per workgroup (+5-9 % in tools/ubench/gemm_loop.hip,
 // -6 ... +10 % in the kernel: no net gain), start-time stagger of the workgroups by quarters of a tile period, so that
 // the epilogues (HBM writes) of some CUs fall under the main loops of others (profiles/r03_gemm_stagger_ab_b2.txt: +-2 %
 // at K = 320, slower everywhere else: the CUs are not in lockstep to begin with).
 constexpr int PP_TILES_LINEAR = 8;
-constexpr int PP_CONV_TAP_INNER = 4;     // convolution K order: the taps of a 64-channel slab back to back (A/B; see gemm_pp.hip)
+// Convolution K order of the persistent kernel.  Default since round 4: the ks * ks taps of one 64-channel slab back to back —
+// their windows are shifts of the same input rows, so the taps after the first hit L2 and the input of a tile is fetched from
+// the fabric once instead of once per tap: 64x64 / 32x32 convolutions 3.8 - 7.1x -> 1.3 - 2.0x their algorithmic bytes, the
+// launch mix 1.88x -> 1.67x, at the same GEMM time per forward (profiles/r04_gemm_traffic_by_shape*.txt; single convolutions
+// 0 - 3 % slower in isolation, profiles/r04_gemm_conv_order_ab_b2.txt).  Bit 4 restores the tap-major order (all channel slabs
+// of a tap, then the next tap), which sums K in the order of the tile kernels: bit-identical results, used by the equality
+// tests and for A/B runs.
+constexpr int PP_CONV_TAP_MAJOR = 4;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 

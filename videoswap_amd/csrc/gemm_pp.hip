@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     bool need_setup = true;
     int t_kh = 0, t_kw = 0, t_c = 0;             // conv: filter tap / channel base of the next slab
     bool t_second = false, t_dirty = true, t_src_dirty = true;
-    const bool tap_inner = CONV && (flags & PP_CONV_TAP_INNER) != 0;
+    const bool tap_inner = CONV && (flags & PP_CONV_TAP_MAJOR) == 0;
     int t_bit = 0, t_re = 0, t_ro = 0, t_ce = 0, t_co = 0;     // tap bit; byte delta of the tap's row / column for an even / odd window origin
     int i_m0 = 0;                                // first row of the tile being staged
     unsigned i_rowB = 0;                         // (first B row of the tile) * pitch
@@ -770,7 +770,7 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     p.tiles_n = (int)(cols / 320);
     p.tiles_total = (int)(((p.M + bm - 1) / bm) * p.tiles_n);
     // option "pp_sched" (env VSX_PP_SCHED): PP_* bits (tile walk)
-    p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_INNER));
+    p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_MAJOR));
     const bool conv = p.a_mode == 1;
     const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0);
 #define VSX_PP_CASE(TM_, CONV_, EPI_) \
