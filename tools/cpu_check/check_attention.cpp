@@ -15,6 +15,7 @@
 
 alignas(16) static unsigned char cpuhip_dyn_lds[160 * 1024];
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
+#define __log2f(x) log2f(x)
 static inline int __all(int pred) {                      // wave vote (all 64 lanes take part, as on the hardware)
     const int lane = (int)(cpuhip::ctx.tid.x & 63);
     cpuhip::ctx.wave_slots[lane] = pred ? 1.f : 0.f;
