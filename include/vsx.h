@@ -112,9 +112,22 @@ typedef struct vsx_gemm_desc {
        normalised tensor is never written or re-read.  Plain (a_mode 0), unbatched GEMMs only; NULL / NULL = off. */
     const void* rowscale;
     const void* colvec;
+    /* ABI v8: row statistics of the OUTPUT, for a LayerNorm that follows this Linear (the producer side of the fold above:
+       every LayerNorm input of the UNet is the output of a GEMM — proj_in, attention to_out + residual; attention.py:182,
+       199,205, motion_module.py:213,219).  rowstats = fp32 [M][rowstats_parts][2] = (sum, sum of squares) of the ROUNDED
+       fp16 outputs of row m over column part p, written by the epilogue that stores them; vsx_row_stats_combine turns the
+       parts into the [M][2] rowscale of the consumer (one pass over 48 bytes per row instead of vsx_row_stats' pass over
+       the whole row).  Only the persistent kernel emits them (plain GEMM, N a multiple of 320, epilogue = bias and / or
+       residual or row vector): ASK FIRST with vsx_gemm_rowstats_parts(d) — the number of parts this launch will write
+       (6 per 320 columns), 0 = it will not (keep rowstats NULL and use vsx_row_stats).  NULL / 0 = off. */
+    void* rowstats;
+    int64_t rowstats_parts;
 } vsx_gemm_desc;
 
 int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream);
+/* parts per row the launch described by d would write into d->rowstats (see above); the answer does not depend on
+   d->rowstats / d->rowstats_parts themselves */
+int64_t vsx_gemm_rowstats_parts(const vsx_gemm_desc* d);
 /* bytes of `workspace` that make split-K possible for this problem (0: it would not be split) */
 int64_t vsx_gemm_workspace(const vsx_gemm_desc* d);
 
@@ -142,6 +155,10 @@ int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg, int64_t ro
 /* Row statistics of x[M, C] for a LayerNorm folded into its consumer GEMM (vsx_gemm_desc.rowscale):
  * stats[m] = (rstd_m, -rstd_m * mean_m), rstd = 1/sqrt(var + eps), fp32 statistics as in vsx_layernorm. */
 int vsx_row_stats(const void* x, int64_t M, int64_t C, float eps, float* stats, vsx_stream_t stream);
+/* the same stats[m] from the partial sums a producing GEMM wrote (vsx_gemm_desc.rowstats): parts [M][nparts][2] fp32 =
+ * (sum, sum of squares) over disjoint column parts that cover the C columns; variance = E[x^2] - mean^2 in fp32. */
+int vsx_row_stats_combine(const float* parts, int64_t M, int64_t nparts, int64_t C, float eps, float* stats,
+                          vsx_stream_t stream);
 
 /* K4: LayerNorm over the last dim of x[M, C] (attention.py:182,199,205; motion_module.py:213,219).
  * If pe != NULL, adds pe[((m / rows_per_frame) % frames) + frame_offset][c] (fp16 [max_len, C]) to

@@ -284,6 +284,54 @@ def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched, adden
         assert rel_err(old, ref) < 2e-3
 
 
+@pytest.mark.parametrize('M,N,K,res', [(65536, 320, 320, True), (65536, 320, 320, False), (16384, 640, 640, True),
+                                       (65500, 320, 328, True), (8192, 1280, 1280, True), (4096, 1280, 1280, True)])
+def test_row_statistics_from_the_producing_gemm(M, N, K, res):
+    """vsx_gemm_desc.rowstats (ABI 8): the persistent kernel's epilogue also writes (sum, sum of squares) of every output
+    row over 6 column parts per 320 columns; vsx_row_stats_combine turns them into the (rstd, -rstd * mean) pairs the
+    consumer of a folded LayerNorm reads.  Checked against the partial sums of the stored output, against vsx_row_stats
+    on that output, and end to end: LayerNorm -> Linear from the producer's statistics equals the standalone-pass form.
+    Launches the persistent kernel does not take (M = 4096: tile kernels) must simply not offer statistics."""
+    import ctypes
+    from videoswap_amd import _lib
+    x, w, b = rnd(M, K, seed=150), rnd(N, K, seed=151, scale=K ** -0.5), rnd(N, seed=152)
+    r = rnd(M, N, seed=153, scale=3.0) if res else None
+    y = ops().linear(x, w, b, residual=r, row_stats=True)
+    plain = ops().linear(x, w, b, residual=r)
+    assert torch.equal(y, plain), 'emitting the statistics must not change the output'
+    parts = getattr(y, '_vsx_rowparts', None)
+    if M == 4096:
+        assert parts is None
+        return
+    assert parts is not None and parts.shape == (M, (N // 320) * 6, 2)
+    cols = []
+    for h in range(N // 160):
+        cols += [(h * 160, 64), (h * 160 + 64, 64), (h * 160 + 128, 32)]
+    yf = y.float()
+    want = torch.stack([torch.stack([yf[:, c0:c0 + wd].sum(1), (yf[:, c0:c0 + wd] ** 2).sum(1)], -1) for c0, wd in cols], 1)
+    assert (parts - want).abs().max() <= 1e-3 * (1 + want.abs().max())
+    lib = _lib.load()
+    st = torch.empty(M, 2, dtype=torch.float32, device=y.device)
+    _lib.check(lib.vsx_row_stats_combine(ops()._p(parts), M, parts.shape[1], N, 1e-5, ops()._p(st), ops()._stream()), 'combine')
+    ref = torch.empty_like(st)
+    _lib.check(lib.vsx_row_stats(ops()._p(y), M, N, 1e-5, ops()._p(ref), ops()._stream()), 'row_stats')
+    assert (st[:, 0] / ref[:, 0] - 1).abs().max() < 1e-4                         # rstd
+    assert (st[:, 1] - ref[:, 1]).abs().max() < 1e-3 * (1 + ref[:, 1].abs().max())      # -rstd * mean
+    # end to end through the fold: LayerNorm(y) @ w2^T with the statistics taken from the producer / from the pass over y
+    from videoswap_amd.layers import LayerNorm
+    ln = LayerNorm(N).to(y.device, torch.float16)
+    with torch.no_grad():
+        ln.weight.copy_(rnd(N, seed=154).abs() + 0.5)
+        ln.bias.copy_(rnd(N, seed=155))
+    w2 = rnd(320, N, seed=156, scale=N ** -0.5)
+    a = ops().linear(ln(y, defer=True), w2)
+    bare = y.clone()                                  # (a clone carries no statistics)
+    b2 = ops().linear(ln(bare, defer=True), w2)
+    ref2 = F.layer_norm(y.float(), (N,), ln.weight.float(), ln.bias.float(), 1e-5) @ w2.float().t()
+    assert rel_err(a, ref2) < 2e-3 and rel_err(b2, ref2) < 2e-3
+    assert rel_err(a, b2.float(), l2_tol=2e-4, row_tol=2e-3) < 2e-3
+
+
 def test_persistent_kernel_is_deterministic_and_repeatable():
     """Back-to-back launches on one stream reuse the LDS ring and the barrier pattern: 20 launches, identical bits."""
     x, w, b = rnd(65536, 320, seed=103), rnd(960, 320, seed=104, scale=320 ** -0.5), rnd(960, seed=105)

@@ -155,7 +155,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert _lib.load().vsx_abi_version() == _lib.VSX_ABI_VERSION
-    assert ctypes.sizeof(_lib.GemmDesc) == 44 * 8      # ABI v4: + pad_lo, pad_hi; ABI 7: + rowscale, colvec
+    assert ctypes.sizeof(_lib.GemmDesc) == 46 * 8      # ABI v4: + pad_lo, pad_hi; ABI 7: + rowscale, colvec; ABI 8: + rowstats, rowstats_parts
 
 
 def test_ops_refuse_cpu_tensors():

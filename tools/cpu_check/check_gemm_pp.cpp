@@ -105,6 +105,11 @@ static void run_case(const Case& c) {
         p.b_bytes = (unsigned)(((brows - 1) * c.K + c.K) * 2);
         p.splitk = 1;
         if (!pp_supported(p)) { printf("%s: not eligible\n", c.name); return; }
+        // row statistics of the output (EPI_STATS: plain / addend epilogues only): 6 parts per 320 columns
+        const bool stats = pp_rowstats_ok(p);
+        const long nparts = stats ? (c.N / 320) * 6 : 0;
+        std::vector<float> parts((size_t)c.M * nparts * 2, -1.f);
+        if (stats) { p.rowstats = parts.data(); p.rowstats_parts = (int)nparts; }
         g_sched = sched;
         cpuhip_oob_reads = 0;
         const int rc = launch_pp(p, c.bm, nullptr);
@@ -114,7 +119,19 @@ static void run_case(const Case& c) {
             num += d * d;
             den += want[i] * want[i];
         }
-        const double rel = sqrt(num / den);
+        double rel = sqrt(num / den);
+        if (stats) {            // every part = (sum, sum of squares) of the ROUNDED outputs over its columns: widths 64, 64, 32 per 160
+            double worst = 0;
+            for (long m = 0; m < c.M; ++m)
+                for (long q = 0; q < nparts; ++q) {
+                    const long col0 = (q / 3) * 160 + (q % 3) * 64, w = (q % 3) == 2 ? 32 : 64;
+                    double s1 = 0, s2 = 0;
+                    for (long n = col0; n < col0 + w; ++n) { const double v = (double)C[m * c.N + n]; s1 += v; s2 += v * v; }
+                    worst = std::max(worst, fabs((double)parts[(m * nparts + q) * 2] - s1) / (1.0 + fabs(s1)));
+                    worst = std::max(worst, fabs((double)parts[(m * nparts + q) * 2 + 1] - s2) / (1.0 + fabs(s2)));
+                }
+            if (worst > 1e-5) { printf("%s: row statistics off by %.2e\n", c.name, worst); rel = 1.0; }
+        }
         bool same = true;
         if (first.empty()) first = C;
         else same = memcmp(first.data(), C.data(), C.size() * sizeof(half_t)) == 0;

@@ -46,6 +46,7 @@ class GemmDesc(Structure):
         ('workspace', c_void_p), ('workspace_bytes', c_int64),
         ('pad_lo', c_int64), ('pad_hi', c_int64),
         ('rowscale', c_void_p), ('colvec', c_void_p),
+        ('rowstats', c_void_p), ('rowstats_parts', c_int64),
     ]
 
 
@@ -57,12 +58,14 @@ PROTOTYPES = {
     'vsx_set_option': (c_int, [c_char_p, c_int64]),
     'vsx_gemm_f16': (c_int, [POINTER(GemmDesc), c_void_p]),
     'vsx_gemm_workspace': (c_int64, [POINTER(GemmDesc)]),
+    'vsx_gemm_rowstats_parts': (c_int64, [POINTER(GemmDesc)]),
     'vsx_groupnorm_chunks': (c_int64, [c_int64, c_int64]),
     'vsx_groupnorm_stats': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                     c_void_p]),
     'vsx_groupnorm_apply': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                     c_int64, c_int64, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     'vsx_row_stats': (c_int, [c_void_p, c_int64, c_int64, c_float, c_void_p, c_void_p]),
+    'vsx_row_stats_combine': (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p, c_void_p]),
     'vsx_layernorm': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int64,
                               c_int64, c_void_p, c_void_p]),
     'vsx_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int64] * 14 + [c_float, c_void_p]),

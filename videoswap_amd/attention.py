@@ -156,7 +156,8 @@ class _FusedProcessor:
         o = ops.attention(q, k, vt, attn.heads, attn.scale, kv_div=kv_div, nk=nk)
         if attn.residual_connection:
             residual = hidden_states if residual is None else ops.axpy(residual, hidden_states)
-        out = attn.to_out[0](o, residual=residual)
+        # every output of a fused attention feeds the block's next LayerNorm (attention.py:199,205): statistics ride along
+        out = attn.to_out[0](o, residual=residual, row_stats=True)
         return out
 
 
@@ -303,4 +304,4 @@ class VanillaAttentionProcessor(nn.Module):
         else:
             q, k, v = attn.to_q(x).view(-1, c), attn.to_k(x).view(-1, c), attn.to_v(x).view(-1, c)
         o = ops.temporal_attention(q, k, v, b, frames, fk, hw, attn.heads, attn.scale).view(bf, hw, c)
-        return attn.to_out[0](o, residual=residual)
+        return attn.to_out[0](o, residual=residual, row_stats=True)      # the next LayerNorm of the block follows (motion_module.py:213-219)

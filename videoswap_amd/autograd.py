@@ -116,7 +116,7 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db, dres, None
 
 
-def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
+def linear(x, weight, bias=None, residual=None, geglu=False, out=None, row_stats=False):      # (row_stats: inference-only hint)
     if out is not None:
         raise NotImplementedError('linear(out=...) on the gradient path')
     return _Linear.apply(x, weight, bias, residual, geglu)

@@ -965,7 +965,22 @@ extern "C" int64_t vsx_gemm_workspace(const vsx_gemm_desc* d) {
     return s > 1 ? (int64_t)s * d->M * d->N * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
+static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, bool dry, int64_t* parts_out);
+
+extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream) { return gemm_impl(d, stream, false, nullptr); }
+
+// How many row-statistics parts would this launch write?  The same checks and the same kernel choice as the launch itself
+// (gemm_impl stops in front of it); 0 whenever the problem does not go to the persistent kernel with an eligible epilogue.
+extern "C" int64_t vsx_gemm_rowstats_parts(const vsx_gemm_desc* d) {
+    int64_t parts = 0;
+    if (!d || d->M <= 0) return 0;
+    vsx_gemm_desc probe = *d;
+    probe.rowstats = nullptr;
+    probe.rowstats_parts = 0;
+    return gemm_impl(&probe, nullptr, true, &parts) == VSX_OK ? parts : 0;
+}
+
+static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dry, int64_t* parts_out) {
     hipStream_t stream = (hipStream_t)stream_;
     VSX_REQUIRE(d != nullptr, VSX_E_BADSHAPE, "gemm: null descriptor");
     VSX_REQUIRE(d->M >= 0 && d->N > 0 && d->K > 0, VSX_E_BADSHAPE, "gemm: bad M/N/K %ld/%ld/%ld",
@@ -1083,7 +1098,7 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     auto blocks = [&](long bm, long bn) { return ((d->M + bm - 1) / bm) * ((cols + bn - 1) / bn) * nbatch; };
     int rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool sample = g_prof.on && !g_prof.paused && g_prof.n < g_prof.max_samples &&
+    const bool sample = !dry && g_prof.on && !g_prof.paused && g_prof.n < g_prof.max_samples &&
                         (g_prof.seen++ % g_prof.stride) == 0;
     if (sample) {
         if ((long)g_prof.ev->size() < 2 * (g_prof.n + 1)) {
@@ -1110,9 +1125,25 @@ extern "C" int vsx_gemm_f16(const vsx_gemm_desc* d, vsx_stream_t stream_) {
     // tiles for the plain GEMMs with about ONE such tile per CU (the 640 / 1280-wide projections at M = 16 384 / 8 192 and
     // ff2 at those sizes: 7-10 % over the tile kernels; the convolutions of that size stay on the tile kernels)
     const long t128 = blocks(128, 320);
-    if (pp_ok && pp != 3 && (blocks(256, 320) >= 192 || (pp == 2 && blocks(256, 320) >= 64))) {
+    const bool pp256 = pp_ok && pp != 3 && (blocks(256, 320) >= 192 || (pp == 2 && blocks(256, 320) >= 64));
+    const bool pp128 = !pp256 && pp_ok && ((pp >= 2 && t128 >= 32) || (pp == 1 && p.a_mode != 1 && t128 >= 240 && t128 <= 272));
+    // row statistics of the output (vsx.h, ABI 8): only the persistent kernel's staged row passes produce them
+    const long stat_parts = (pp256 || pp128) && pp_rowstats_ok(p) ? (cols / 320) * 6 : 0;
+    if (dry) {
+        *parts_out = stat_parts;
+        return VSX_OK;
+    }
+    if (d->rowstats != nullptr) {
+        VSX_REQUIRE(stat_parts > 0 && d->rowstats_parts == stat_parts, VSX_E_UNSUPPORTED,
+                    "gemm: rowstats with %ld parts, but this launch writes %ld (ask vsx_gemm_rowstats_parts first)",
+                    (long)d->rowstats_parts, stat_parts);
+        VSX_REQUIRE(vsx_aligned16(d->rowstats), VSX_E_BADSHAPE, "gemm: rowstats must be 16-byte aligned");
+        p.rowstats = (float*)d->rowstats;
+        p.rowstats_parts = (int)stat_parts;
+    }
+    if (pp256) {
         rc = launch_pp(p, 256, stream);
-    } else if (pp_ok && ((pp >= 2 && t128 >= 32) || (pp == 1 && p.a_mode != 1 && t128 >= 240 && t128 <= 272))) {
+    } else if (pp128) {
         rc = launch_pp(p, 128, stream);
     } else if (force_tile() && wide) {
         p.ws = (float*)d->workspace;

@@ -18,6 +18,8 @@ struct GemmParams {
     // LayerNorm folded into the GEMM (vsx.h: rowscale / colvec): out = rs[m] * acc + rt[m] * c1[n] (+ bias ...)
     const float* rowscale;      // [M][2] = (rstd, -rstd * mean) of the A rows, or nullptr
     const float* colvec;        // [N] (geglu: [2N]) = sum_k B[n][k]
+    float* rowstats;            // [M][rowstats_parts][2] partial (sum, sum of squares) of the rounded outputs, or nullptr
+    int rowstats_parts;
     long M, N, K;
     long lda, ldb, ldc, ldr;
     long a_bs0, a_bs1, b_bs0, b_bs1, c_bs0, c_bs1, r_bs0, r_bs1;
@@ -71,6 +73,7 @@ long gemm_option(const char* name);
 
 // gemm_pp.hip: persistent ping-pong kernel (256x320 / 128x320 tiles).  `bm` selects the row tile.
 bool pp_supported(const GemmParams& p);
+bool pp_rowstats_ok(const GemmParams& p);   // can the persistent kernel's epilogue of this problem emit row statistics?
 int launch_pp(GemmParams& p, int bm, hipStream_t stream);
 
 }  // namespace vsxg

@@ -138,11 +138,13 @@ __device__ __forceinline__ void pre_fetch(const PreSrc& ps, const int lane, cons
 // LayerNorm folded into the GEMM — lane l holds (rstd, -rstd * mean) of row mblk + l % 32 in st_rs / st_rt; a pass
 // fetches its row's pair with two cross-lane reads.  Same fp32 operation order as gemm.hip's epilogue (scale, LayerNorm
 // identity, bias, row vector | residual).
-template <int CW, int PD, bool LN>           // CW: chunk width in output columns: 64, 32 or 16; PD: ring depth (0: no addend)
+// STATS: the pass also writes (sum, sum of squares) of its row's ROUNDED outputs over the chunk's columns into
+// p->rowstats[m][part] (vsx.h, ABI 8): the LPR lanes that share a row add up with log2(LPR) cross-lane steps.
+template <int CW, int PD, bool LN, bool STATS = false>   // CW: chunk width in output columns: 64, 32 or 16; PD: ring depth (0: no addend)
 __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, const int lane, const int mblk,
                                               const int ncol, const float* cst, const PreSrc& ps, h8* pre,
                                               const int fbase, const int nf, const float st_rs = 1.f,
-                                              const float st_rt = 0.f) {
+                                              const float st_rt = 0.f, const int part = 0) {
     constexpr bool ADD = PD > 0;
     constexpr int STRIDE = CW + 4;                  // floats per staged row
     constexpr int LPR = CW / 8;                     // lanes per row (8 columns each)
@@ -189,6 +191,22 @@ __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, con
 #pragma unroll
         for (int e = 0; e < 8; ++e) pk[e] = (half_t)o[e];
         if (m < Mi) *reinterpret_cast<h8*>(cp + ((unsigned)m * ldc + (unsigned)n)) = pk;
+        if constexpr (STATS) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)pk[e];
+                s1 += f;
+                s2 = __builtin_fmaf(f, f, s2);
+            }
+#pragma unroll
+            for (int d = LPR / 2; d > 0; d >>= 1) {       // the LPR lanes of a row are adjacent: fixed-shape tree
+                s1 += __shfl_xor(s1, d, 64);
+                s2 += __shfl_xor(s2, d, 64);
+            }
+            if (col8 == 0 && m < Mi)
+                *reinterpret_cast<f2v*>(p->rowstats + ((size_t)m * (unsigned)p->rowstats_parts + (unsigned)part) * 2) = f2v{s1, s2};
+        }
     }
 }
 
@@ -197,12 +215,17 @@ __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, con
 constexpr int EPI_ADD = 1;          // + residual, or + row vector (one of the two: prefetched ring)
 constexpr int EPI_LN = 2;           // LayerNorm folded into the GEMM (rowscale / colvec)
 constexpr int EPI_GEGLU = 4;        // h * gelu(g)
+constexpr int EPI_STATS = 8;        // row statistics of the output for a LayerNorm that follows (not with LN / GEGLU)
 
 template <int TM, int EPI, int PD>
 __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, const int mrow0, const int ncol0,
                                             const int gcol0, const int lane) {
     constexpr bool ADD = (EPI & EPI_ADD) != 0, LN = (EPI & EPI_LN) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
+    constexpr bool STATS = (EPI & EPI_STATS) != 0;
+    static_assert(!STATS || (!LN && !GEGLU), "row statistics come from the plain / addend epilogues");
     kparams_t p = kernarg_params();
+    // statistics part of this wave's first chunk: 6 parts per 320 columns = (column half wc) x (chunks of 64, 64, 32 columns)
+    const int part0 = STATS ? (ncol0 / 160) * 3 : 0;
     const int l31 = lane & 31, hi = lane >> 5;
     const float alpha = p->alpha;
     // ---- loads of the tile's constants, issued before anything else.  Column constants: lane l < 40 owns 4 of the wave's
@@ -336,8 +359,8 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
                 if (i == 0 && c == 0) park_constants();
                 __builtin_amdgcn_sched_barrier(0);
                 const float* cc_ = use_cst ? cst + c * 64 : nullptr;
-                if (c < 2) epilogue_rows<64, ADD ? PD : 0, LN>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + c * 4, NF, st_rs[i], st_rt[i]);
-                else epilogue_rows<32, ADD ? PD : 0, LN>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + 8, NF, st_rs[i], st_rt[i]);
+                if (c < 2) epilogue_rows<64, ADD ? PD : 0, LN, STATS>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + c * 4, NF, st_rs[i], st_rt[i], part0 + c);
+                else epilogue_rows<32, ADD ? PD : 0, LN, STATS>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + 8, NF, st_rs[i], st_rt[i], part0 + c);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -694,7 +717,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             const int n0 = geglu ? tile_n * (BN / 2) : tile_n * BN;
             const int stg_off = wave < NFIT ? ((c_g - 1) & 1) * STAGE + wave * EP_BYTES
                                             : 2 * STAGE + (wave - NFIT) * EP_BYTES;
-            constexpr int PD = (EPI & EPI_LN) ? 2 : (CONV ? 3 : 4);      // addend ring depth
+            constexpr int PD = (EPI & EPI_LN) ? 2 : ((CONV || (EPI & EPI_STATS)) ? 3 : 4);      // addend ring depth (what fits without scratch)
             epilogue_pp<TM, EPI, PD>(acc, reinterpret_cast<float*>(smem + stg_off), tile_m * BM + wr * WM, n0 + wc * WN,
                                  n0 + wc * TN * 16, lane);
         }
@@ -747,6 +770,10 @@ extern "C" int vsx_pp_debug_buffer(void* buf) {
 }
 #endif
 
+bool pp_rowstats_ok(const GemmParams& p) {
+    return !p.geglu && p.rowscale == nullptr && p.a_mode == 0 && p.c_mode == 0 && pp_supported(p);
+}
+
 bool pp_supported(const GemmParams& p) {
     // no column edge (N a multiple of the tile), 16-byte epilogue accesses, fast-tap convolutions, 32-bit offsets
     const long cols = p.geglu ? 2 * p.N : p.N;
@@ -772,7 +799,8 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     // option "pp_sched" (env VSX_PP_SCHED): PP_* bits (tile walk)
     p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_MAJOR));
     const bool conv = p.a_mode == 1;
-    const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0);
+    const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0) |
+                    (p.rowstats ? EPI_STATS : 0);
 #define VSX_PP_CASE(TM_, CONV_, EPI_) \
     if ((bm == 256) == (TM_ == 2) && conv == CONV_ && epi == (EPI_)) return launch_one<TM_, CONV_, (EPI_)>(p, stream);
 #define VSX_PP_CASES(TM_)                             \
@@ -783,7 +811,9 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     VSX_PP_CASE(TM_, false, EPI_LN)                   \
     VSX_PP_CASE(TM_, false, EPI_LN | EPI_ADD)         \
     VSX_PP_CASE(TM_, false, EPI_GEGLU)                \
-    VSX_PP_CASE(TM_, false, EPI_GEGLU | EPI_LN)
+    VSX_PP_CASE(TM_, false, EPI_GEGLU | EPI_LN)       \
+    VSX_PP_CASE(TM_, false, EPI_STATS)                \
+    VSX_PP_CASE(TM_, false, EPI_STATS | EPI_ADD)
     VSX_PP_CASES(2)
     VSX_PP_CASES(1)
 #undef VSX_PP_CASES

@@ -330,6 +330,25 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const half_t* __restrict
     }
 }
 
+// Row statistics from the partial sums a producing GEMM's epilogue wrote (vsx_gemm_desc.rowstats): one thread per row adds its
+// nparts (sum, sum of squares) pairs in index order — 8 * nparts contiguous bytes — and writes (rstd, -rstd * mean).
+__global__ __launch_bounds__(256) void row_stats_combine_kernel(const float* __restrict__ parts, long M, int nparts, float inv_c,
+                                                                float eps, float* __restrict__ stats) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float2* pp = reinterpret_cast<const float2*>(parts) + m * nparts;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < nparts; ++i) {
+        const float2 v = pp[i];
+        s1 += v.x;
+        s2 += v.y;
+    }
+    const float mean = s1 * inv_c;
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_c), 0.f);
+    const float rstd = rsqrtf(var + eps);
+    *reinterpret_cast<float2*>(stats + 2 * m) = make_float2(rstd, -rstd * mean);
+}
+
 // in-place row softmax, one wave per row (fp16 storage, fp32 math).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ S, long nrows, int ncols, long ld) {
     const int lane = threadIdx.x & 63;
@@ -457,6 +476,18 @@ extern "C" int vsx_row_stats(const void* x, int64_t M, int64_t C, float eps, flo
     else VSX_RS_LAUNCH(4, 1);
 #undef VSX_RS_LAUNCH
     return vsx_check_launch("vsx_row_stats");
+}
+
+extern "C" int vsx_row_stats_combine(const float* parts, int64_t M, int64_t nparts, int64_t C, float eps, float* stats,
+                                     vsx_stream_t stream) {
+    VSX_REQUIRE(parts && stats, VSX_E_BADSHAPE, "row_stats_combine: null argument");
+    if (M == 0) return VSX_OK;
+    VSX_REQUIRE(M > 0 && nparts > 0 && nparts <= 64 && C > 0, VSX_E_BADSHAPE, "row_stats_combine: M=%ld nparts=%ld C=%ld", (long)M,
+                (long)nparts, (long)C);
+    VSX_REQUIRE((((uintptr_t)parts) & 7) == 0 && (((uintptr_t)stats) & 7) == 0, VSX_E_BADSHAPE, "row_stats_combine: 8-byte alignment");
+    hipLaunchKernelGGL(row_stats_combine_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, (long)M,
+                       (int)nparts, 1.0f / (float)C, eps, stats);
+    return vsx_check_launch("vsx_row_stats_combine");
 }
 
 extern "C" int vsx_softmax_rows(void* S, int64_t nrows, int64_t ncols, int64_t ld, vsx_stream_t stream) {

@@ -47,17 +47,18 @@ class StepInvariantCache:
 
 
 class Linear(nn.Linear):
-    """y = x W^T + b on the MFMA GEMM; optional fused residual add."""
+    """y = x W^T + b on the MFMA GEMM; optional fused residual add.  `row_stats`: a LayerNorm consumes the result — the
+    GEMM's epilogue may then emit the row statistics with it (ops.linear)."""
 
-    def forward(self, x, residual=None):
-        return ops.linear(x, self.weight, self.bias, residual=residual)
+    def forward(self, x, residual=None, row_stats=False):
+        return ops.linear(x, self.weight, self.bias, residual=residual, row_stats=row_stats)
 
 
 class PointwiseConv(nn.Conv2d):
     """1x1 nn.Conv2d parameters ([out, in, 1, 1]) applied to channels-last tokens (attention.py:65,93)."""
 
-    def forward(self, x, residual=None):
-        return ops.linear(x, self.weight, self.bias, residual=residual)
+    def forward(self, x, residual=None, row_stats=False):
+        return ops.linear(x, self.weight, self.bias, residual=residual, row_stats=row_stats)
 
 
 class Identity(nn.Module):

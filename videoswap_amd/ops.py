@@ -99,6 +99,10 @@ def gemm(desc):
 LN_FUSE = os.environ.get('VSX_LN_FUSE', '1') != '0'     # 0: every LayerNorm runs as its own kernel (A/B runs)
 
 
+# VSX_ROW_STATS_PRODUCER=0: LayerNorm row statistics always by the standalone pass (A/B runs)
+ROW_STATS_FROM_PRODUCER = os.environ.get('VSX_ROW_STATS_PRODUCER', '1') != '0'
+
+
 class DeferredLN:
     """A LayerNorm that has not been applied: `x` is the RAW activation, and the Linear(s) consuming the normalised tensor
     (attention.py:182,199,205 norm1/2/3 -> to_q / to_k / to_v / GEGLU; motion_module.py:213,219) apply it inside their
@@ -113,6 +117,11 @@ class DeferredLN:
         self.x, self.gamma, self.beta, self.eps = x, gamma, beta, eps
         self.pe, self.rows_per_frame, self.frames, self.frame_offset = pe, rows_per_frame, frames, frame_offset
         self._shared = _shared if _shared is not None else {}          # stats / materialised tensor, shared by reshapes
+        # partial row sums the producing GEMM hung on its output (they describe the ROWS: reshapes keep them)
+        if 'row_parts' not in self._shared:
+            self._shared['row_parts'] = getattr(x, '_vsx_rowparts', None)
+
+    row_parts = property(lambda self: self._shared.get('row_parts'))
 
     shape = property(lambda self: self.x.shape)
     dtype = property(lambda self: self.x.dtype)
@@ -138,13 +147,20 @@ class DeferredLN:
         return self._like(self.x.view(*shape))
 
     def stats(self):
-        """[M, 2] fp32 = (rstd, -rstd * mean) per row (vsx_row_stats), computed once"""
+        """[M, 2] fp32 = (rstd, -rstd * mean) per row, computed once: from the partial sums the GEMM that produced x
+        wrote in its epilogue (`linear(..., row_stats=True)` hangs them on its output tensor) where there are any,
+        otherwise by a pass over x (vsx_row_stats)"""
         st = self._shared.get('stats')
         if st is None:
             C = self.x.shape[-1]
             M = self.x.numel() // C
             st = torch.empty(M, 2, dtype=torch.float32, device=self.x.device)
-            check(_lib.load().vsx_row_stats(_p(self.x), M, C, float(self.eps), _p(st), _stream()), 'vsx_row_stats')
+            parts = self.row_parts
+            if parts is not None and parts.shape[0] == M and ROW_STATS_FROM_PRODUCER:
+                check(_lib.load().vsx_row_stats_combine(_p(parts), M, parts.shape[1], C, float(self.eps), _p(st), _stream()),
+                      'vsx_row_stats_combine')
+            else:
+                check(_lib.load().vsx_row_stats(_p(self.x), M, C, float(self.eps), _p(st), _stream()), 'vsx_row_stats')
             self._shared['stats'] = st
         return st
 
@@ -215,11 +231,13 @@ def _ln_pe_rows(hit, weight, ln, M):
     return rv, ln.rows_per_frame
 
 
-def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
+def linear(x, weight, bias=None, residual=None, geglu=False, out=None, row_stats=False):
     """y = x @ weight.T (+bias) (+residual); geglu: weight is [2N,K], y = h * gelu(g).
 
     x [..., K] -> [..., N].  Replaces nn.Linear / 1x1 conv / diffusers GEGLU.  `x` may be a DeferredLN: the LayerNorm is
-    then applied inside the GEMM.
+    then applied inside the GEMM.  `row_stats`: a LayerNorm follows — where the launch can (vsx_gemm_rowstats_parts), its
+    epilogue also writes per-row partial sums of the output, which then travel with the returned tensor
+    (`y._vsx_rowparts`, picked up by layers.LayerNorm / DeferredLN.stats); a hint, never an obligation.
     """
     ln = x if isinstance(x, DeferredLN) else None
     if ln is not None:
@@ -261,8 +279,16 @@ def linear(x, weight, bias=None, residual=None, geglu=False, out=None):
         d.residual = residual.data_ptr(); d.ldr = N
     d.geglu = 1 if geglu else 0
     d.alpha = 1.0
+    parts = None
+    if row_stats and ln is None and not geglu and ROW_STATS_FROM_PRODUCER:
+        nparts = int(_lib.load().vsx_gemm_rowstats_parts(ctypes.byref(d)))
+        if nparts > 0:
+            parts = torch.empty(M, nparts, 2, dtype=torch.float32, device=x.device)
+            d.rowstats, d.rowstats_parts = parts.data_ptr(), nparts
     gemm(d)
     del keep
+    if parts is not None:
+        out._vsx_rowparts = parts
     return out
 
 

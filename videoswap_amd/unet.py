@@ -177,7 +177,7 @@ class Transformer3DModel(nn.Module):
         result holds both halves (they part at the cross-attention)."""
         bf, h, w, c = x.shape
         y = self.norm(x, bf)
-        y = self.proj_in(y.view(bf, h * w, c))
+        y = self.proj_in(y.view(bf, h * w, c), row_stats=True)       # norm1 of the block follows
         for block in self.transformer_blocks:
             y = block(y, encoder_hidden_states=encoder_hidden_states, video_length=geo.F,
                       split_after_self=split_after_self)
@@ -251,7 +251,7 @@ class TemporalTransformer3DModel(nn.Module):
     def forward(self, x, geo):
         bf, h, w, c = x.shape
         y = self.norm(x, bf)
-        y = self.proj_in(y.view(bf, h * w, c))
+        y = self.proj_in(y.view(bf, h * w, c), row_stats=True)       # the first LayerNorm of the block follows
         shard = geo.site_shard
         if shard is None or not shard.use_sites(h * w):
             for block in self.transformer_blocks:
