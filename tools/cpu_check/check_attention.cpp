@@ -25,9 +25,6 @@ static inline int __all(int pred) {                      // wave vote (all 64 la
     cpuhip::ctx.wave_bar->arrive_and_wait();
     return r;
 }
-typedef _Float16 cpuhip_h2 __attribute__((ext_vector_type(2)));
-static inline float cpuhip_fdot2(cpuhip_h2 a, cpuhip_h2 b, float acc) { return acc + (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1]; }
-#define __builtin_amdgcn_fdot2(a, b, acc, clamp) cpuhip_fdot2(a, b, acc)
 
 #include "common.h"
 

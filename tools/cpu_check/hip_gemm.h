@@ -128,3 +128,8 @@ namespace vsxg {
 template <int N>
 inline void wait_vmcnt() { cpuhip_wait_vmcnt(N); }
 }
+
+// v_dot2_f32_f16: acc + a0 * b0 + a1 * b1 in fp32 (the products of two fp16 values are exact in fp32)
+typedef _Float16 cpuhip_h2 __attribute__((ext_vector_type(2)));
+static inline float cpuhip_fdot2(cpuhip_h2 a, cpuhip_h2 b, float acc) { return acc + (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1]; }
+#define __builtin_amdgcn_fdot2(a, b, acc, clamp) cpuhip_fdot2(a, b, acc)
