@@ -106,6 +106,21 @@ static void run_layernorm(const char* name, long M, long C, bool pe, long rows_p
         char nm[128];
         snprintf(nm, sizeof nm, "  row statistics (rstd, -rstd * mean) of the same rows");
         report(nm, vsx_row_stats(x.data(), M, C, 1e-5f, st.data(), nullptr), wstats, dbl(st), 1e-5);
+        // the same pairs from partial sums over column parts of 64, 64, 32, ... columns (what a producing GEMM writes)
+        std::vector<long> edges = {0};
+        while (edges.back() < C) edges.push_back(std::min(C, edges.back() + ((edges.size() % 3) == 0 ? 32 : 64)));
+        const long np = (long)edges.size() - 1;
+        std::vector<float> parts((size_t)M * np * 2);
+        for (long m = 0; m < M; ++m)
+            for (long q = 0; q < np; ++q) {
+                float s1 = 0.f, s2 = 0.f;
+                for (long c = edges[q]; c < edges[q + 1]; ++c) { const float v = (float)x[m * C + c]; s1 += v; s2 += v * v; }
+                parts[(m * np + q) * 2] = s1;
+                parts[(m * np + q) * 2 + 1] = s2;
+            }
+        std::fill(st.begin(), st.end(), -9.f);
+        snprintf(nm, sizeof nm, "  ... combined from %ld partial sums per row", np);
+        report(nm, vsx_row_stats_combine(parts.data(), M, np, C, 1e-5f, st.data(), nullptr), wstats, dbl(st), 1e-4);
     }
 }
 

@@ -1022,7 +1022,9 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
     p.c_img_stride = d->c_img_stride;
 
     const long nbatch = d->batch0 * d->batch1;
-    VSX_REQUIRE(d->M < (1L << 31) && d->N < (1L << 30) && d->M * d->ldc < (1L << 31) &&
+    // (the transposed store of c_mode 1 addresses C with 64-bit offsets, and its ldc is the row length of one image's V^T,
+    // not a pitch of the M rows: B = 2 x 64 frames x 4096 tokens must not trip over M * ldc there)
+    VSX_REQUIRE(d->M < (1L << 31) && d->N < (1L << 30) && (d->c_mode == 1 || d->M * d->ldc < (1L << 31)) &&
                     (!d->residual || d->M * d->ldr < (1L << 31)),
                 VSX_E_UNSUPPORTED, "gemm: M*ldc and M*ldr must be below 2^31 elements");
     {

@@ -346,7 +346,8 @@ __global__ __launch_bounds__(256) void row_stats_combine_kernel(const float* __r
     const float mean = s1 * inv_c;
     const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_c), 0.f);
     const float rstd = rsqrtf(var + eps);
-    *reinterpret_cast<float2*>(stats + 2 * m) = make_float2(rstd, -rstd * mean);
+    stats[2 * m] = rstd;
+    stats[2 * m + 1] = -rstd * mean;
 }
 
 // in-place row softmax, one wave per row (fp16 storage, fp32 math).
