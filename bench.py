@@ -377,7 +377,7 @@ def main():
         'config': {'launch': 'hip-graph' if graphs else 'eager',
                    'workload': (f'BASELINE.json configs[{args.config - 1}]: {args.frames}-frame {lw * 8}x{lh * 8} clip, SD-1.5 UNet3D + '
                                 f'AnimateDiff motion modules, {args.ddim_steps}-step DDIM inversion (B=1) + '
-                                f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B=2), one clip per GPU per step'
+                                f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B=2), ' + ('the ranks share ONE clip per step' if longclip else 'one clip per GPU per step')
                                 + ('; full swap path (VideoSwapPipeline.validation): AttentionStore during the inversion, '
                                    'ED-LoRA merge + per-layer text embeddings [2,16,77,768], point-adapter residuals for '
                                    'sampling steps 0-25, AttentionRefine + latent / self-attention SpatialBlenders '
