@@ -250,6 +250,9 @@ def test_persistent_geglu(M, N, K):
     (32, 16, 16, 1280, 0, 1280, 3, 1, False, 0),   # M = 8192: 128x320 tiles
     (3, 28, 48, 128, 64, 640, 3, 1, False, 0),     # M = 4032 (not a multiple of 128), W = 48: 128x320 tiles
     (100, 6, 8, 128, 0, 320, 3, 1, False, 0),      # 48 rows per image: 32-row blocks that meet two row vectors
+    (16, 32, 32, 640, 0, 640, 3, 1, False, 0),     # W = 32: two image rows per wave (shared A slab, see the test body)
+    (18, 32, 32, 640, 320, 640, 3, 1, False, 8),   # ... two sources, ragged last tile row (72 tiles of 256)
+    (5, 32, 32, 128, 0, 320, 3, 1, False, 0),      # ... 128x320 tiles (M = 5120)
 ])
 def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched, addend):
     """The persistent kernel carries ONE addend through its epilogue ring (time-embedding row vector on a ResNet's first
@@ -270,6 +273,12 @@ def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched, adden
     old, same_order = both_gemm_paths(run)
     ops().set_option('pp_sched', _sched(sched))
     _, new = both_gemm_paths(run)
+    # stride-1 3x3 convolutions with image rows of 32 / 64 / ... pixels stream ONE A slab per filter row and read it at three
+    # row offsets (gemm_pp.hip "SHARED A SLAB"); pp_sched bit 16 keeps a private slab per tap: same products, same order
+    # bit 32: every CU issues the B pieces of a slab in the same order (default: from a per-CU starting point)
+    ops().set_option('pp_sched', _sched(sched) | 16 | 32)
+    _, private_a = both_gemm_paths(run)
+    assert torch.equal(new, private_a)
     ref = conv_ref(x, w, b, stride, x2, ups)
     if rowvec is not None:
         ref = ref + rowvec.float()[:, None, None, :]

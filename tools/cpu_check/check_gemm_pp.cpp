@@ -46,7 +46,7 @@ static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
 struct Case { const char* name; long M, N, K; bool res, geglu; int bm; bool ln = false; };
 
 static int n_bad = 0;
-static std::vector<long> g_scheds = {0, 8, 4, 12};      // pp_sched bits: 8 = linear tile walk instead of the 2-D one; 4 = conv K order tap-major (default: taps of a channel slab back to back)
+static std::vector<long> g_scheds = {0, 8, 4, 12, 16, 32};      // pp_sched bits: 8 = linear tile walk instead of the 2-D one; 4 = conv K order tap-major (default: taps of a channel slab back to back); 16 = a private A slab per tap (default where the shape allows: one A slab per filter row, read at three row offsets); 32 = every CU issues the B pieces of a slab in the same order (default: from a per-CU starting point)
 
 static std::vector<half_t> pack_b(const std::vector<half_t>& w, long rows, long K) {      // [N/8][K/64][8][64]
     std::vector<half_t> out(w.size());
@@ -216,7 +216,8 @@ static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, i
         if (first.empty()) first = C;
         else same = memcmp(first.data(), C.data(), C.size() * sizeof(half_t)) == 0;
         const bool ok = rc == 0 && rel < 3e-3 && same && cpuhip_oob_reads == 0;
-        printf("%-34s bm %3d sched %2ld: rc %d rel-L2 %.2e %s%s%s\n", name, bm, sched, rc, rel,
+        printf("%-34s bm %3d sched %2ld: rc %d rel-L2 %.2e %s%s%s%s\n", name, bm, sched, rc, rel,
+               (p.pp_flags & PP_CONV_ASHIFT_ON) ? "(shared A slab) " : "",
                same ? "" : "DIFFERS from the first schedule ", cpuhip_oob_reads ? "reads past the tensor " : "",
                ok ? "ok" : "FAIL");
         if (!ok) ++n_bad;
@@ -259,6 +260,21 @@ int main(int argc, char** argv) {
         run_conv("conv3x3 3x6x8 64->320", 3, 6, 8, 64, 0, 320, 1, 0, 256);
     if (only < 0 || only == ncases + 5) run_conv("conv3x3 2x8x8 64->320, bias only", 2, 8, 8, 64, 0, 320, 1, 0, 256, false);
     if (only < 0 || only == ncases + 6) run_conv("conv3x3 2x8x8 64->320, bias only, 128-row", 2, 8, 8, 64, 0, 320, 1, 0, 128, false);
+    // shared A slab (W a power of two >= 32): image rows of 32 / 64 pixels, several channel slabs, two sources, a ragged last tile
+    if (only < 0 || only == ncases + 7) run_conv("conv3x3 1x16x32 64->320", 1, 16, 32, 64, 0, 320, 1, 0, 256);
+    if (only < 0 || only == ncases + 8) run_conv("conv3x3 2x8x32 128+64->320", 2, 8, 32, 128, 64, 320, 1, 0, 256);
+    if (only < 0 || only == ncases + 9) run_conv("conv3x3 1x8x64 64->320", 1, 8, 64, 64, 0, 320, 1, 0, 256);
+    if (only < 0 || only == ncases + 10) run_conv("conv3x3 1x12x32 128->320 128-row", 1, 12, 32, 128, 0, 320, 1, 0, 128);
+    if (only < 0 || only == ncases + 11) run_conv("conv3x3 3x4x32 64->320 (ragged)", 3, 4, 32, 64, 0, 320, 1, 0, 256, false);
+    if (only < 0 || only == ncases + 12) run_conv("conv3x3 1x6x64 64+64->320 128-row", 1, 6, 64, 64, 64, 320, 1, 0, 128);
+    // ... and three tiles per workgroup (8 workgroups, 24 tiles): the A ring's parity across tile boundaries for an odd and an
+    // even number of A slabs per tile, next to the epilogue's staging area
+    if (only == ncases + 13 || only == ncases + 14) {
+        cpuhip_num_cus = 8;
+        if (only == ncases + 13) run_conv("conv3x3 1x192x32 64->320, 3 tiles/wg", 1, 192, 32, 64, 0, 320, 1, 0, 256);
+        else run_conv("conv3x3 1x96x64 64+64->320, 3 tiles/wg", 1, 96, 64, 64, 64, 320, 1, 0, 256);
+        cpuhip_num_cus = 24;
+    }
     if (only < 0) {          // the 2-D tile walk visits every tile exactly once (any tile count, ragged last super-row)
         int bad = 0;
         for (int tn : {1, 2, 6, 8, 12, 16, 24, 32, 40, 44})

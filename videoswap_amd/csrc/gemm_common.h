@@ -55,6 +55,13 @@ constexpr int PP_TILES_LINEAR = 8;
 // of a tap, then the next tap), which sums K in the order of the tile kernels: bit-identical results, used by the equality
 // tests and for A/B runs.
 constexpr int PP_CONV_TAP_MAJOR = 4;
+// Shared A slab of the stride-1 3x3 convolutions (gemm_pp.hip, "SHARED A SLAB": the three taps of a filter row read one
+// A slab at three row offsets).  On wherever the shape allows it; option bit 16 keeps a private A slab per tap (A/B runs,
+// the equality test).  PP_CONV_ASHIFT_ON is set by launch_pp, never by the option.
+constexpr int PP_CONV_PRIVATE_A = 16;
+constexpr int PP_CONV_ASHIFT_ON = 1 << 16;
+// The B pieces of a slab are issued from a per-CU starting point (gemm_pp.hip, `w5`); bit 32 restores the common order (A/B runs).
+constexpr int PP_B_COMMON_ORDER = 32;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 

@@ -371,11 +371,12 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
     }
 }
 
-// TM: 32-row blocks per wave (tile = 128*TM x 320).  CONV: implicit-GEMM A loader (a_mode 1) or plain row-major A.
+// TM: 32-row blocks per wave (tile = 128*TM x 320).  CONV: 0 = plain row-major A, 1 = implicit-GEMM A loader (a_mode 1),
+// 2 = the same with one A slab per filter row ("SHARED A SLAB" below: stride-1 3x3, taps-inner order).
 // EPI: epilogue kind (EPI_* bits).  This wave's 2*TM + 5 DMA pieces of a slab are issued in the load phases
 // L0 [0, CUT1), L1 [CUT1, CUT2), L2 [CUT2, ..) (A pieces first: they come from HBM / Infinity Cache, the weights from
 // L2); L3 issues nothing.  (Other cut points were measured in round 3 — profiles/r03_gemm_sched_ab_b2.txt — and dropped.)
-template <int TM, bool CONV, int EPI>
+template <int TM, int CONV, int EPI>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused, const int tiles_total) {
     constexpr int CUT1 = 3, CUT2 = TM == 2 ? 6 : 5;
     constexpr int TN = 5;
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     constexpr int STAGE = (BM + BN) * 128;      // bytes per ring slot
     constexpr int NFIT = STAGE / EP_BYTES;      // waves whose epilogue staging area fits a ring slot
     constexpr int OOB_OFF = (int)0x80000000;
+    constexpr int ZERO_OFF = 2 * STAGE + (8 - NFIT) * EP_BYTES;     // 128 zero bytes behind the staging areas (shared A slab)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     kparams_t p = kernarg_params();
@@ -435,7 +437,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     const int nk = (K + BK - 1) / BK;
     const int ktail_from = K - (nk - 1) * BK;            // last slab: k offsets >= this are beyond K
     const unsigned lda2 = (unsigned)p->lda * 2u, ldb2 = (unsigned)p->ldb * 2u;   // row pitches in bytes
-    const int w5 = wave * GB;                    // this wave's first B piece
+    // this wave's first B piece.  The CUs of an XCD walk the 40 pieces of a B slab from different starting points (an even
+    // rotation: the swizzle parity of a piece stays the wave's own), so that CUs running in step do not ask their L2 for the
+    // same weight lines at the same moment: - 1.3 % GEMM time per forward, - 3 ... 5 % on the long-K convolutions and on
+    // ff2 / proj at the 64 x 64 level (profiles/r04_gemm_b_rotation_ab_b2.txt); PP_B_COMMON_ORDER switches it off
+    const int w5 = wave * GB + ((p->pp_flags & PP_B_COMMON_ORDER) ? 0 : 2 * (((int)(blockIdx.x >> 3) * 7) % 20));
     const int Ngeglu = (int)p->N;
 
     // per-lane parts of the operand offsets (bytes): row-in-piece * pitch + swizzled k slot
@@ -458,7 +464,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     bool need_setup = true;
     int t_kh = 0, t_kw = 0, t_c = 0;             // conv: filter tap / channel base of the next slab
     bool t_second = false, t_dirty = true, t_src_dirty = true;
-    const bool tap_inner = CONV && (flags & PP_CONV_TAP_MAJOR) == 0;
+    const bool tap_inner = CONV == 2 || (CONV && (flags & PP_CONV_TAP_MAJOR) == 0);
+    // SHARED A SLAB (stride-1 3x3, W a power of two in [32, BM]; launch_pp decides).  The windows of the taps (kh, 0..2) are
+    // one-pixel shifts of each other, and a tile starts at the first pixel of an image row: the A slab of tap (kh, 1) is
+    // streamed ONCE per (channel slab, kh) and the MFMAs of kw = 0 / 2 read their fragments one LDS row lower / higher; the
+    // lanes whose pixel sits at the left / right image edge read a zero row instead.  A slab (32 KiB of 72) then arrives with
+    // every third slab only: 152 instead of 216 KiB into LDS per three slabs of a kernel that is bound by operand delivery.
+    // The A ring runs on its own parity: A slab k of a tile lives in slot (first slab of the tile + k) & 1 — the slot of the
+    // tile's first B slab for k = 0, so that the epilogue's staging area (the slot of the LAST slab) never holds the next
+    // tile's operands; k + 1 never shares a slot with k, nor the next tile's k = 0 with this tile's last (nk / 3 - 1 and nk
+    // differ in parity for every nk = 3q).
+    constexpr bool ashift = CONV == 2;
+    const int wmask = ashift ? p->W - 1 : 0;
+    int i_aslot = 0, i_sbA = 0;
+    bool i_hasA = true;
     int t_bit = 0, t_re = 0, t_ro = 0, t_ce = 0, t_co = 0;     // tap bit; byte delta of the tap's row / column for an even / odd window origin
     int i_m0 = 0;                                // first row of the tile being staged
     unsigned i_rowB = 0;                         // (first B row of the tile) * pitch
@@ -494,6 +513,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             }
             t_kh = 0; t_kw = 0; t_c = 0; t_second = false; t_dirty = true;
             t_src_dirty = true;
+            i_aslot = (i_g & 1) ^ 1;            // the tile's first slab toggles it to the slot of its B slab
         }
     };
 
@@ -514,15 +534,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
                 for (int i = 0; i < GA; ++i) a_vb[i] = (a_px[i] * csz + ((i & 1) ? kofs_o : kofs_e)) * 2;
                 t_src_dirty = false;
             }
+            i_hasA = !ashift || t_kw == 0;
+            if (i_hasA) i_aslot ^= 1;
             if (t_dirty) {                      // first slab of a tap (a slab never straddles a tap or the two sources)
                 const int ups = p->ups;
                 const int Ws = ups ? (p->W >> 1) : p->W;
-                t_bit = 3 * t_kh + t_kw;
+                const int kw_e = ashift ? 1 : t_kw;         // shared A slab: the window of the centre column
+                t_bit = 3 * t_kh + kw_e;
                 // nearest-2x source: tap k of a window whose origin has parity b reads source row / column (b + k) >> 1
                 t_re = ((ups ? t_kh >> 1 : t_kh) * Ws * csz) * 2;
                 t_ro = ((ups ? (t_kh + 1) >> 1 : t_kh) * Ws * csz) * 2;
-                t_ce = ((ups ? t_kw >> 1 : t_kw) * csz) * 2;
-                t_co = ((ups ? (t_kw + 1) >> 1 : t_kw) * csz) * 2;
+                t_ce = ((ups ? kw_e >> 1 : kw_e) * csz) * 2;
+                t_co = ((ups ? (kw_e + 1) >> 1 : kw_e) * csz) * 2;
                 t_dirty = false;
             }
             i_second = t_second;
@@ -563,6 +586,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             i_soffB = i_rowB + (unsigned)kt * (BK * 2);
         }
         i_sb = (i_g & 1) * STAGE;
+        i_sbA = ashift ? i_aslot * STAGE : i_sb;
         i_tail = (kt == nk - 1) && ktail_from < BK;
         ++i_g;
         if (++i_kt == nk) { i_kt = 0; ++i_t; need_setup = true; }
@@ -570,10 +594,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     auto issue_piece = [&](const int q) {           // q is a compile-time constant at every call site
         if (q < GA) {
             const int kofs = (q & 1) ? kofs_o : kofs_e;             // wave * GA is even
-            lptr_t dst = (lptr_t)(smem + i_sb + (wave * GA + q) * 1024);
+            lptr_t dst = (lptr_t)(smem + (CONV ? i_sbA : i_sb) + (wave * GA + q) * 1024);
             if constexpr (CONV) {
+                if (!i_hasA) return;            // shared A slab: it came with the slab of kw = 0
                 const int mk = a_mk[q < GA ? q : 0];
-                const int dlt = ((mk & 512) ? t_ro : t_re) + ((mk & 1024) ? t_co : t_ce);
+                const int dlt = ashift ? t_re + t_ce          // no nearest-2x source: one row / column term
+                                       : ((mk & 512) ? t_ro : t_re) + ((mk & 1024) ? t_co : t_ce);
                 const bool in = ((mk >> t_bit) & 1) != 0 && !(i_tail && kofs >= ktail_from);
                 const int v = in ? a_vb[q < GA ? q : 0] + dlt : OOB_OFF;
                 if (i_second) {
@@ -589,7 +615,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             }
         } else {
             const int j = q - GA;
-            const int pj = w5 + j;                                   // piece index inside the 320-row B tile
+            const int pj = w5 + j < BN / 8 ? w5 + j : w5 + j - BN / 8;      // piece index inside the 320-row B tile
             const bool odd = (pj & 1) != 0;
             const int kofs = odd ? kofs_o : kofs_e;
             // row of the weight matrix behind tile row pj*8 + lrow: plain n0 + pj*8 + lrow; GEGLU interleaves h and g
@@ -616,10 +642,26 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     const int b_addr = BM * 128 + (wc * WN + l31) * 128 + fr;
 
     h8 af[TM], bf[TN];
+    // shared A slab: absolute A fragment offsets of the slab being multiplied (A slot, shifted row or the zero row), set per slab
+    int aoff[ashift ? TM : 1];
+    int c_kw = 0, c_aslot = 0;
+    auto shared_a_setup = [&]() {
+        const int r = l31 + c_kw - 1;                            // -1 .. 32: the rows of an edge lane are never read
+        const int base = c_aslot * STAGE + (wr * WM + r) * 128 + ((hi ^ ((r >> 1) & 7)) * 16);
+#pragma unroll
+        for (int i = 0; i < (ashift ? TM : 1); ++i) {
+            const int row0 = wr * WM + i * 32;                   // tile row of the block's first row (a tile starts at w = 0)
+            const bool edge = (c_kw == 0 && l31 == 0 && (row0 & wmask) == 0) ||
+                              (c_kw == 2 && l31 == 31 && ((row0 + 32) & wmask) == 0);
+            aoff[i] = edge ? ZERO_OFF : base + i * 4096;
+        }
+    };
     auto ldfrag = [&](const int slot_off, const int ks) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-            af[i] = *reinterpret_cast<const h8*>(smem + slot_off + ((a_addr ^ (ks * 32)) + i * 4096));
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (ashift) af[i] = *reinterpret_cast<const h8*>(smem + (aoff[i] ^ (ks * 32)));
+            else af[i] = *reinterpret_cast<const h8*>(smem + slot_off + ((a_addr ^ (ks * 32)) + i * 4096));
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             bf[j] = *reinterpret_cast<const h8*>(smem + slot_off + ((b_addr ^ (ks * 32)) + j * 4096));
@@ -646,6 +688,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if constexpr (ashift) {
+        if (tid < 32) reinterpret_cast<float*>(smem + ZERO_OFF)[tid] = 0.f;
+        lgkm0();
+    }
     // ---- prologue: slab 0 of the first tile, all pieces at once ----
     slab_prep();
     issue_range(0, NPIECE);
@@ -665,6 +711,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             const int so = (c_g & 1) * STAGE;
             i_on = i_t < n_my;
             if (i_on) slab_prep();              // the slab that streams in while this one is multiplied
+            if constexpr (ashift) {
+                if (kt == 0) { c_kw = 0; c_aslot = c_g & 1; }
+                else if (++c_kw == 3) { c_kw = 0; c_aslot ^= 1; }
+                shared_a_setup();
+            }
             // ---- k-step 0 ----
             ldfrag(so, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -741,10 +792,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     if (G == 0) bar();                          // matches group 1's extra barrier at the start
 }
 
-template <int TM, bool CONV, int EPI>
+template <int TM, int CONV, int EPI>
 int launch_one(const GemmParams& p, hipStream_t stream) {
     constexpr size_t stage = (size_t)(128 * TM + 320) * 128;
-    constexpr size_t smem = 2 * stage + (8 - stage / EP_BYTES) * EP_BYTES;     // ring + the staging areas behind it
+    constexpr size_t smem = 2 * stage + (8 - stage / EP_BYTES) * EP_BYTES + (CONV == 2 ? 128 : 0);     // ring + the staging areas behind it (+ the zero row)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
@@ -801,23 +852,30 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     p.tiles_n = (int)(cols / 320);
     p.tiles_total = (int)(((p.M + bm - 1) / bm) * p.tiles_n);
     // option "pp_sched" (env VSX_PP_SCHED): PP_* bits (tile walk)
-    p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_MAJOR));
-    const bool conv = p.a_mode == 1;
+    p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_MAJOR | PP_CONV_PRIVATE_A | PP_B_COMMON_ORDER));
+    int conv = p.a_mode == 1 ? 1 : 0;
+    // shared A slab (gemm_pp_kernel: "SHARED A SLAB"): stride-1 3x3 convolutions in the taps-inner order whose image rows
+    // are a power of two of at least one 32-row MFMA block and at most one tile, so that every tile starts at w = 0
+    if (conv && (p.pp_flags & (PP_CONV_TAP_MAJOR | PP_CONV_PRIVATE_A)) == 0 && p.ks == 3 && p.stride == 1 && p.ups == 0 &&
+        p.pad == 1 && p.Wo == p.W && p.Ho == p.H && p.W >= 32 && p.W <= bm && (p.W & (p.W - 1)) == 0)
+        p.pp_flags |= PP_CONV_ASHIFT_ON, conv = 2;
     const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0) |
                     (p.rowstats ? EPI_STATS : 0);
 #define VSX_PP_CASE(TM_, CONV_, EPI_) \
     if ((bm == 256) == (TM_ == 2) && conv == CONV_ && epi == (EPI_)) return launch_one<TM_, CONV_, (EPI_)>(p, stream);
 #define VSX_PP_CASES(TM_)                             \
-    VSX_PP_CASE(TM_, true, 0)                         \
-    VSX_PP_CASE(TM_, true, EPI_ADD)                   \
-    VSX_PP_CASE(TM_, false, 0)                        \
-    VSX_PP_CASE(TM_, false, EPI_ADD)                  \
-    VSX_PP_CASE(TM_, false, EPI_LN)                   \
-    VSX_PP_CASE(TM_, false, EPI_LN | EPI_ADD)         \
-    VSX_PP_CASE(TM_, false, EPI_GEGLU)                \
-    VSX_PP_CASE(TM_, false, EPI_GEGLU | EPI_LN)       \
-    VSX_PP_CASE(TM_, false, EPI_STATS)                \
-    VSX_PP_CASE(TM_, false, EPI_STATS | EPI_ADD)
+    VSX_PP_CASE(TM_, 2, 0)                        \
+    VSX_PP_CASE(TM_, 2, EPI_ADD)                  \
+    VSX_PP_CASE(TM_, 1, 0)                        \
+    VSX_PP_CASE(TM_, 1, EPI_ADD)                  \
+    VSX_PP_CASE(TM_, 0, 0)                        \
+    VSX_PP_CASE(TM_, 0, EPI_ADD)                  \
+    VSX_PP_CASE(TM_, 0, EPI_LN)                   \
+    VSX_PP_CASE(TM_, 0, EPI_LN | EPI_ADD)         \
+    VSX_PP_CASE(TM_, 0, EPI_GEGLU)                \
+    VSX_PP_CASE(TM_, 0, EPI_GEGLU | EPI_LN)       \
+    VSX_PP_CASE(TM_, 0, EPI_STATS)                \
+    VSX_PP_CASE(TM_, 0, EPI_STATS | EPI_ADD)
     VSX_PP_CASES(2)
     VSX_PP_CASES(1)
 #undef VSX_PP_CASES
