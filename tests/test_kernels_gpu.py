@@ -275,7 +275,7 @@ def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched, adden
     _, new = both_gemm_paths(run)
     # stride-1 3x3 convolutions with image rows of 32 / 64 / ... pixels stream ONE A slab per filter row and read it at three
     # row offsets (gemm_pp.hip "SHARED A SLAB"); pp_sched bit 16 keeps a private slab per tap: same products, same order
-    # bit 32: every CU issues the B pieces of a slab in the same order (default: from a per-CU starting point)
+    # bit 32: every CU issues the pieces of a slab in the same order (default: from a per-CU starting point)
     ops().set_option('pp_sched', _sched(sched) | 16 | 32)
     _, private_a = both_gemm_paths(run)
     assert torch.equal(new, private_a)

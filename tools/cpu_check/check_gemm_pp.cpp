@@ -46,7 +46,7 @@ static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
 struct Case { const char* name; long M, N, K; bool res, geglu; int bm; bool ln = false; };
 
 static int n_bad = 0;
-static std::vector<long> g_scheds = {0, 8, 4, 12, 16, 32};      // pp_sched bits: 8 = linear tile walk instead of the 2-D one; 4 = conv K order tap-major (default: taps of a channel slab back to back); 16 = a private A slab per tap (default where the shape allows: one A slab per filter row, read at three row offsets); 32 = every CU issues the B pieces of a slab in the same order (default: from a per-CU starting point)
+static std::vector<long> g_scheds = {0, 8, 4, 12, 16, 32};      // pp_sched bits: 8 = linear tile walk instead of the 2-D one; 4 = conv K order tap-major (default: taps of a channel slab back to back); 16 = a private A slab per tap (default where the shape allows: one A slab per filter row, read at three row offsets); 32 = every CU issues the pieces of a slab in the same order (default: from a per-CU starting point)
 
 static std::vector<half_t> pack_b(const std::vector<half_t>& w, long rows, long K) {      // [N/8][K/64][8][64]
     std::vector<half_t> out(w.size());

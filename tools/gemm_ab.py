@@ -100,6 +100,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--reps', type=int, default=4)
     ap.add_argument('--scheds', default='', help='comma-separated pp_sched values: compare option bits instead of tile sizes')
+    ap.add_argument('--auto-scheds', default='', help='comma-separated pp_sched values under the automatic dispatch (gemm_pp = 1)')
     ap.add_argument('--bm', type=int, default=256, choices=(128, 256), help='row tile of the --scheds comparison')
     ap.add_argument('--kinds', default='', help="comma-separated subset of plain,geglu,conv (default: all)")
     args = ap.parse_args()
@@ -109,6 +110,8 @@ def main():
             n = int(n)
             return f'pp{args.bm}/s{n}'
         variants = [('tile', 0, 0)] + [(label(n), 2 if args.bm == 256 else 3, int(n)) for n in args.scheds.split(',')]
+    if args.auto_scheds:        # the product's own dispatch (gemm_pp = 1) under different pp_sched bits; 'tile' stays the baseline column
+        variants = [('tile', 0, 0)] + [(f'auto/s{int(n)}', 1, int(n)) for n in args.auto_scheds.split(',')]
     print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
     print(f'{"shape":44s} {"n":>3s} ' + ' '.join(f'{v[0]:>9s}' for v in variants) + '   best TF/s  speedup  fwd-ms tile -> best')
     tot_old = tot_best = 0.0
@@ -130,8 +133,10 @@ def main():
             dev = {k: float((outs[k].float() - ref).norm() / ref.norm()) for k in bad}
             print(f'# {name}: variants differing from the tile kernels (rel-L2): ' + ', '.join(f'{k} {v:.2e}' for k, v in dev.items()))
         del outs
-        for _ in range(args.rounds):
-            for v in variants:
+        for rnd in range(args.rounds):
+            # the order rotates round by round: a variant's time depends on what ran just before it (the later columns of a
+            # fixed order came out 1 - 4 % faster on the long convolutions, profiles/r04_gemm_rotation_ab_b*.txt)
+            for v in variants[rnd % len(variants):] + variants[:rnd % len(variants)]:
                 ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2])
                 ts[v[0]].append(time_once(fns[v[0]], args.reps))
         med = {k: sorted(x)[len(x) // 2] * 1000.0 for k, x in ts.items()}

@@ -60,8 +60,9 @@ constexpr int PP_CONV_TAP_MAJOR = 4;
 // the equality test).  PP_CONV_ASHIFT_ON is set by launch_pp, never by the option.
 constexpr int PP_CONV_PRIVATE_A = 16;
 constexpr int PP_CONV_ASHIFT_ON = 1 << 16;
-// The B pieces of a slab are issued from a per-CU starting point (gemm_pp.hip, `w5`); bit 32 restores the common order (A/B runs).
-constexpr int PP_B_COMMON_ORDER = 32;
+// The A (and, in the plain GEMMs, B) pieces of a slab are issued from a per-CU starting point (gemm_pp.hip, "PIECE ROTATION");
+// bit 32 restores the common order (A/B runs).
+constexpr int PP_COMMON_ORDER = 32;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 

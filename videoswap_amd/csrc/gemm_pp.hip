@@ -437,11 +437,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     const int nk = (K + BK - 1) / BK;
     const int ktail_from = K - (nk - 1) * BK;            // last slab: k offsets >= this are beyond K
     const unsigned lda2 = (unsigned)p->lda * 2u, ldb2 = (unsigned)p->ldb * 2u;   // row pitches in bytes
-    // this wave's first B piece.  The CUs of an XCD walk the 40 pieces of a B slab from different starting points (an even
-    // rotation: the swizzle parity of a piece stays the wave's own), so that CUs running in step do not ask their L2 for the
-    // same weight lines at the same moment: - 1.3 % GEMM time per forward, - 3 ... 5 % on the long-K convolutions and on
-    // ff2 / proj at the 64 x 64 level (profiles/r04_gemm_b_rotation_ab_b2.txt); PP_B_COMMON_ORDER switches it off
-    const int w5 = wave * GB + ((p->pp_flags & PP_B_COMMON_ORDER) ? 0 : 2 * (((int)(blockIdx.x >> 3) * 7) % 20));
+    // PIECE ROTATION.  The CUs of an XCD run in step and share panels: the column tiles of one row tile read the same A
+    // rows, the row tiles of one column tile the same weights.  Every CU therefore starts its walk over the BM / 8 A pieces
+    // and (plain GEMMs) the 40 B pieces of a slab somewhere else — an even rotation, so that the swizzle parity of a piece
+    // stays the wave's own — and the CUs do not ask their L2 for the same lines at the same moment.  Position-balanced A/B,
+    // B = 2 (profiles/r04_gemm_rotation_ab_b2.txt): A rotation - 4.5 % on qkv 320->960, - 5.5 % on geglu 320->1280 (A panel
+    // shared by 3 / 8 column tiles), neutral where A is private; B rotation - 2 ... 3.6 % on ff2 1280->320, proj 1280->1280,
+    // ff2 5120->1280, + 1 ... 2 % on the convolutions (which keep the common B order); GEMM time of a forward - 1.15 %.
+    // PP_COMMON_ORDER switches both off.  (The same rotation in the tile kernels changed nothing: call r04l.)
+    const bool rot_on = (p->pp_flags & PP_COMMON_ORDER) == 0;
+    const int w5 = wave * GB + (rot_on && !CONV ? 2 * (((int)(blockIdx.x >> 3) * 7) % 20) : 0);       // this wave's first B piece
+    const int wa = wave * GA + (rot_on ? 2 * (((int)(blockIdx.x >> 3) * 5) % (BM / 16)) : 0);         // ... and A piece
+    auto a_piece = [&](const int q) { return wa + q < BM / 8 ? wa + q : wa + q - BM / 8; };
     const int Ngeglu = (int)p->N;
 
     // per-lane parts of the operand offsets (bytes): row-in-piece * pitch + swizzled k slot
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             const int Hs = ups ? (H >> 1) : H, Ws = ups ? (W >> 1) : W;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
-                const int m = i_m0 + (wave * GA + i) * 8 + lrow;
+                const int m = i_m0 + a_piece(i) * 8 + lrow;
                 const unsigned mm = m < Mi ? (unsigned)m : 0u;
                 const unsigned img = mm / hw;
                 const unsigned rem = mm - img * hw;
@@ -582,7 +589,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
                 }
             }
         } else {
-            i_soffA = (unsigned)(i_m0 + wave * GA * 8) * lda2 + (unsigned)kt * (BK * 2);
+            i_soffA = (unsigned)i_m0 * lda2 + (unsigned)kt * (BK * 2);
             i_soffB = i_rowB + (unsigned)kt * (BK * 2);
         }
         i_sb = (i_g & 1) * STAGE;
@@ -593,8 +600,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     };
     auto issue_piece = [&](const int q) {           // q is a compile-time constant at every call site
         if (q < GA) {
-            const int kofs = (q & 1) ? kofs_o : kofs_e;             // wave * GA is even
-            lptr_t dst = (lptr_t)(smem + (CONV ? i_sbA : i_sb) + (wave * GA + q) * 1024);
+            const int kofs = (q & 1) ? kofs_o : kofs_e;             // wave * GA and the rotation are even
+            const int pa = a_piece(q);
+            lptr_t dst = (lptr_t)(smem + (CONV ? i_sbA : i_sb) + pa * 1024);
             if constexpr (CONV) {
                 if (!i_hasA) return;            // shared A slab: it came with the slab of kw = 0
                 const int mk = a_mk[q < GA ? q : 0];
@@ -608,9 +616,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, (int)i_soffA, 0, 0);
                 }
             } else {
-                const bool ok = (i_m0 + (wave * GA + q) * 8 + lrow < Mi) && !(i_tail && kofs >= ktail_from);
+                const bool ok = (i_m0 + pa * 8 + lrow < Mi) && !(i_tail && kofs >= ktail_from);
                 const int v = ok ? ((q & 1) ? va_o : va_e) : OOB_OFF;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, (int)(i_soffA + (unsigned)(q * 8) * lda2),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, (int)(i_soffA + (unsigned)(pa * 8) * lda2),
                                                          0, 0);
             }
         } else {
@@ -852,7 +860,7 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     p.tiles_n = (int)(cols / 320);
     p.tiles_total = (int)(((p.M + bm - 1) / bm) * p.tiles_n);
     // option "pp_sched" (env VSX_PP_SCHED): PP_* bits (tile walk)
-    p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_MAJOR | PP_CONV_PRIVATE_A | PP_B_COMMON_ORDER));
+    p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_MAJOR | PP_CONV_PRIVATE_A | PP_COMMON_ORDER));
     int conv = p.a_mode == 1 ? 1 : 0;
     // shared A slab (gemm_pp_kernel: "SHARED A SLAB"): stride-1 3x3 convolutions in the taps-inner order whose image rows
     // are a power of two of at least one 32-row MFMA block and at most one tile, so that every tile starts at w = 0
