@@ -48,7 +48,8 @@ const char* vsx_source_digest(void);
 /* Tuning / test switch (process-wide, not thread-safe against concurrent launches): "gemm_pp" = 0 never / 1 default /
  * 2 always-when-eligible use of the persistent ping-pong GEMM kernel; "pp_sched" = its option bits (8: linear tile walk; 4: convolutions sum K
  * tap-major like the tile kernels instead of taps-inner; 16: a private A slab per convolution tap; 32: common piece order in every CU).  Results
- * are identical for every setting except bit 4 (same arithmetic; bit 4 selects another fp32 summation order of the same products). */
+ * are identical for every setting except bit 4 (same arithmetic; bit 4 selects another fp32 summation order of the same products).
+ * "tile_tune" (diagnostics, tools/small_m_sweep.py) forces a tile / ring depth / K-slice count of the workgroup-per-tile kernels. */
 int vsx_set_option(const char* name, int64_t value);
 
 /* ------------------------------------------------------------------------------------------

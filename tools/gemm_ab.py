@@ -100,6 +100,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--reps', type=int, default=4)
     ap.add_argument('--scheds', default='', help='comma-separated pp_sched values: compare option bits instead of tile sizes')
+    ap.add_argument('--variants', default='', help='comma-separated name:gemm_pp:pp_sched:tile_tune')
     ap.add_argument('--auto-scheds', default='', help='comma-separated pp_sched values under the automatic dispatch (gemm_pp = 1)')
     ap.add_argument('--bm', type=int, default=256, choices=(128, 256), help='row tile of the --scheds comparison')
     ap.add_argument('--kinds', default='', help="comma-separated subset of plain,geglu,conv (default: all)")
@@ -110,6 +111,8 @@ def main():
             n = int(n)
             return f'pp{args.bm}/s{n}'
         variants = [('tile', 0, 0)] + [(label(n), 2 if args.bm == 256 else 3, int(n)) for n in args.scheds.split(',')]
+    if args.variants:           # free form: name:gemm_pp:pp_sched:tile_tune (option "tile_tune": gemm.hip)
+        variants = [('tile', 0, 0)] + [(v.split(':')[0],) + tuple(int(x) for x in v.split(':')[1:]) for v in args.variants.split(',')]
     if args.auto_scheds:        # the product's own dispatch (gemm_pp = 1) under different pp_sched bits; 'tile' stays the baseline column
         variants = [('tile', 0, 0)] + [(f'auto/s{int(n)}', 1, int(n)) for n in args.auto_scheds.split(',')]
     print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
@@ -124,7 +127,7 @@ def main():
         ts = {v[0]: [] for v in variants}
         outs = {}
         for v in variants:                      # warm every variant (first launch sets the LDS attribute)
-            ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2])
+            ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2]); ops.set_option('tile_tune', v[3] if len(v) > 3 else 0)
             outs[v[0]] = fns[v[0]]()
         torch.cuda.synchronize()
         bad = [k for k, o in outs.items() if not torch.equal(o, outs['tile'])]
@@ -137,7 +140,7 @@ def main():
             # the order rotates round by round: a variant's time depends on what ran just before it (the later columns of a
             # fixed order came out 1 - 4 % faster on the long convolutions, profiles/r04_gemm_rotation_ab_b*.txt)
             for v in variants[rnd % len(variants):] + variants[:rnd % len(variants)]:
-                ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2])
+                ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2]); ops.set_option('tile_tune', v[3] if len(v) > 3 else 0)
                 ts[v[0]].append(time_once(fns[v[0]], args.reps))
         med = {k: sorted(x)[len(x) // 2] * 1000.0 for k, x in ts.items()}
         best = min(med, key=med.get)
@@ -146,7 +149,7 @@ def main():
         print(f'{name:44s} {count:3d} ' + ' '.join(f'{med[v[0]]:9.1f}' for v in variants) +
               f'   {flop / med[best] / 1e6:7.1f}  {med["tile"] / med[best]:6.2f}x  {best:9s}'
               f' {med["tile"] * count / 1000:6.2f} -> {med[best] * count / 1000:6.2f}', flush=True)
-    ops.set_option('gemm_pp', 1); ops.set_option('pp_sched', 0)
+    ops.set_option('gemm_pp', 1); ops.set_option('pp_sched', 0); ops.set_option('tile_tune', 0)
     print(f'# GEMM time per forward (listed shapes): tile kernels {tot_old:.2f} ms, best-of {tot_best:.2f} ms')
 
 

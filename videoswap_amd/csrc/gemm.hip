@@ -38,6 +38,15 @@
 
 using namespace vsxg;
 
+// Diagnostics only (tools/tile_probe.py, tools/gemm_timing.py, tools/small_m_sweep.py): option "tile_tune" (initial value
+// from VSX_TUNE_TILE) = tile + 16 * deep + 256 * splits.  tile 1|2|3 forces the 128x320 / 128x160 / 256x320 tile for problems
+// whose column count is a multiple of 320, 4|5|6 the 128x128 / 64x128 / 64x64 tile for any; deep = 1: four ring slots instead of
+// two for the 128x160 tile; splits > 0: that many K slices (128x320 tiles + combine) where split-K is possible at all.
+static long tile_tune() { return vsxg::gemm_option("tile_tune"); }
+static long force_tile() { return tile_tune() & 15; }
+static bool tune_deep() { return (tile_tune() & 16) != 0; }
+static int tune_splits() { return (int)((tile_tune() >> 8) & 15); }
+
 namespace {
 
 // BK (K slab of 64 halfs: LDS rows are 128 B = one full L2 line per row), GemmParams, lptr_t, wait_vmcnt: gemm_common.h
@@ -824,8 +833,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 // 256 CUs with output tiles alone; slicing K gives every CU a 128x320 tile to work on.  Returns the slice count (1 =
 // no split) for a problem whose wide tiles would number `tiles`.
 inline int plan_splitk(const vsx_gemm_desc* d, long tiles, bool eligible) {
-    if (!eligible || tiles >= 160) return 1;
     const long nk = (d->K + BK - 1) / BK;
+    if (eligible && tune_splits() > 0) return tune_splits() <= nk ? tune_splits() : (int)nk;
+    if (!eligible || tiles >= 160) return 1;
     int s = (int)((256 + tiles - 1) / tiles);
     if (s > 8) s = 8;
     while (s > 1 && nk / s < 12) --s;     // keep >= 12 slabs (768 k) per slice
@@ -850,11 +860,16 @@ int launch(const GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_tile(GemmParams& p, long M, long cols, long nbatch, hipStream_t stream) {
+int launch_tile(GemmParams& p, long M, long cols, long nbatch, hipStream_t stream, bool deep = false) {
     p.tiles_n = (int)((cols + BN - 1) / BN);
     const long tiles_m = (M + BM - 1) / BM;
     // ring depth: two 128-byte-row slabs for the big tiles (57-74 KiB per slab), four for the small ones
     constexpr int NST = ((BM + BN) * 128 * 4 <= 96 * 1024) ? 4 : 2;
+    // `deep` (128x160 only): four slots = one workgroup per CU with three slabs in flight, for launches that put at most
+    // one workgroup on a CU anyway (two slots: two workgroups of 72 KiB per CU hide each other's latency)
+    if constexpr (BM == 128 && BN == 160) {
+        if (deep && p.c_mode != 1) return launch<BM, BN, WAVES_M, WAVES_N, true, 4>(p, tiles_m, nbatch, stream);
+    }
     if (p.c_mode == 1) return launch<BM, BN, WAVES_M, WAVES_N, false, NST>(p, tiles_m, nbatch, stream);
     return launch<BM, BN, WAVES_M, WAVES_N, true, NST>(p, tiles_m, nbatch, stream);
 }
@@ -910,21 +925,11 @@ extern "C" int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* t
     return VSX_OK;
 }
 
-// Diagnostics only (tools/tile_probe.py, tools/gemm_timing.py): VSX_TUNE_TILE=1|2|3 forces the 128x320 / 128x160 /
-// 256x320 tile (no split-K) for problems whose column count is a multiple of 320.
-static long force_tile() {
-    static long v = -1;
-    if (v < 0) {
-        const char* e = getenv("VSX_TUNE_TILE");
-        v = e ? atol(e) : 0;
-    }
-    return v;
-}
-
 namespace vsxg {
 namespace {
 struct Option { const char* name; const char* env; long value; bool init; };
 Option g_options[] = {{"gemm_pp", "VSX_GEMM_PP", 1, false}, {"pp_sched", "VSX_PP_SCHED", 0, false},
+                      {"tile_tune", "VSX_TUNE_TILE", 0, false},
                       {"attn_qb", "VSX_ATTN_QB", 0, false}};
 Option* find_option(const char* name) {
     for (auto& o : g_options)
@@ -1147,11 +1152,14 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
         rc = launch_pp(p, 256, stream);
     } else if (pp128) {
         rc = launch_pp(p, 128, stream);
-    } else if (force_tile() && wide) {
+    } else if (force_tile() && (wide || force_tile() >= 4)) {
         p.ws = (float*)d->workspace;
         if (force_tile() == 1) rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);
-        else if (force_tile() == 2) rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);
-        else rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
+        else if (force_tile() == 2) rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream, tune_deep());
+        else if (force_tile() == 3) rc = launch_tile<256, 320, 8, 2>(p, d->M, cols, nbatch, stream);
+        else if (force_tile() == 4) rc = launch_tile<128, 128, 2, 2>(p, d->M, cols, nbatch, stream);
+        else if (force_tile() == 5) rc = launch_tile<64, 128, 2, 2>(p, d->M, cols, nbatch, stream);
+        else rc = launch_tile<64, 64, 2, 2>(p, d->M, cols, nbatch, stream);
     } else if (splits > 1 && d->workspace != nullptr &&
         d->workspace_bytes >= (int64_t)splits * d->M * d->N * (int64_t)sizeof(float)) {
         const long nk = (d->K + BK - 1) / BK;
@@ -1173,7 +1181,11 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
         // 4 waves, 32x160 per wave, two workgroups per CU (74 KiB of LDS each): one's epilogue and prologue overlap
         // with the other's main loop, and its registers leave room to prefetch the residual.  Since the 128-byte-row
         // slabs it is at least as fast as the 8-wave 128x320 tile on every UNet shape.
-        rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream);
+        // at most one workgroup per CU (<= 256 of them): nothing to overlap with, so four ring slots instead of two
+        // (profiles/r04_gemm_small_m_sweep.txt: proj 1280->1280 at M = 4096 35.2 -> 32.9 us, qk 1280->2560 at M = 2048 - 7 %)
+        rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream, blocks(128, 160) <= 256);
+    } else if (cols % 160 == 0 && blocks(128, 160) >= 176 && !p.geglu && p.c_mode == 0) {
+        rc = launch_tile<128, 160, 4, 1>(p, d->M, cols, nbatch, stream, true);      // qkv 1280->3840 at M = 1024: - 9 %
     } else if (wide && blocks(128, 320) >= 200) {
         rc = launch_tile<128, 320, 4, 2>(p, d->M, cols, nbatch, stream);    // 8 waves, 32x160 per wave
     } else if (blocks(128, 128) >= 512) {
