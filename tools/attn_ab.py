@@ -39,7 +39,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--reps', type=int, default=3)
-    ap.add_argument('--vars', default='1,2', help='values of the option attn_qb (query blocks per wave)')
+    ap.add_argument('--vars', default='1,2', help='values of the option (attn_qb: query blocks per wave)')
+    ap.add_argument('--option', default='attn_qb', help='the option to vary (attn_qb)')
     args = ap.parse_args()
     variants = [int(v) for v in args.vars.split(',')]
     print(f'# flash attention, median of {args.rounds} rounds x {args.reps} launches; us per launch, TFLOP/s of 4*nb*heads*n*n*d')
@@ -48,12 +49,12 @@ def main():
         fn = lambda: ops.attention(q, k, vt, heads, d ** -0.5)      # noqa: E731
         ts = {x: [] for x in variants}
         for x in variants:
-            ops.set_option('attn_qb', x)
+            ops.set_option(args.option, x)
             fn()
         torch.cuda.synchronize()
-        for _ in range(args.rounds):
-            for x in variants:
-                ops.set_option('attn_qb', x)
+        for rnd in range(args.rounds):
+            for x in variants[rnd % len(variants):] + variants[:rnd % len(variants)]:
+                ops.set_option(args.option, x)
                 ts[x].append(time_once(fn, args.reps))
         flop = 4.0 * nb * heads * n * n * d
         med = {x: sorted(t)[len(t) // 2] * 1000.0 for x, t in ts.items()}
@@ -70,7 +71,7 @@ def main():
         ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).transpose(1, 2).reshape(nb, n, heads * d)
         errs = []
         for x in variants:
-            ops.set_option('attn_qb', x)
+            ops.set_option(args.option, x)
             o = ops.attention(q, k, vt, heads, d ** -0.5).float()
             errs.append(f'qb{x}: rel-L2 {float((o - ref).norm() / ref.norm()):.3e} max {float((o - ref).abs().max()):.2e}')
         print(f'accuracy nb={nb} n={n} d={d}: ' + '  '.join(errs), flush=True)
