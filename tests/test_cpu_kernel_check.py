@@ -58,7 +58,11 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
             ('9', '0'),                          # ... through the GEGLU epilogue (128-row)
             ('15', '0'),                         # 3x3 convolution, two sources, row-vector ring
             ('19', '0'),                         # 48 rows per vector: 32-row blocks that meet two row vectors
-            ('21', '0')]                         # convolution without an addend, 128-row tiles
+            ('21', '0'),                         # convolution without an addend, 128-row tiles
+            ('23', '0,16,32'),                   # image rows of 32 pixels, two sources: ONE A slab per filter row read at three
+                                                 # row offsets (default) = a private slab per tap (16), bit for bit; 32 = every
+                                                 # CU walks the pieces of a slab in the same order
+            ('31', '0,16')]                      # ... image rows as long as the tile, ragged last tile
     # (`make -C tools/cpu_check run` walks every case: the remaining kernel kinds, stride 2, nearest-2x, K tails)
     for case, scheds in runs:
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900)
@@ -66,10 +70,11 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     # ordering hazards: the multi-tile, multi-slab case again with every DMA piece landing as LATE as the kernel's own
     # waits allow (the default run above lands them at issue, the other extreme); see tools/cpu_check/hip_gemm.h
-    r = subprocess.run([exe, '1', '0,8'], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, CPUHIP_DMA='late'))
-    print(r.stdout)
-    assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    for case, scheds in (('1', '0,8'), ('22', '0')):      # ('22': the shared A slab's own ring parity)
+        r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, CPUHIP_DMA='late'))
+        print(r.stdout)
+        assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_gemm_entry_point_runs_on_the_cpu(tmp_path):

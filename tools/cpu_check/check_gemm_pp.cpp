@@ -267,6 +267,10 @@ int main(int argc, char** argv) {
     if (only < 0 || only == ncases + 10) run_conv("conv3x3 1x12x32 128->320 128-row", 1, 12, 32, 128, 0, 320, 1, 0, 128);
     if (only < 0 || only == ncases + 11) run_conv("conv3x3 3x4x32 64->320 (ragged)", 3, 4, 32, 64, 0, 320, 1, 0, 256, false);
     if (only < 0 || only == ncases + 12) run_conv("conv3x3 1x6x64 64+64->320 128-row", 1, 6, 64, 64, 64, 320, 1, 0, 128);
+    // image rows as long as half a tile / a whole tile: the edge lanes are those of the tile's first and last 32-row block only
+    if (only < 0 || only == ncases + 15) run_conv("conv3x3 1x4x128 64->320", 1, 4, 128, 64, 0, 320, 1, 0, 256);
+    if (only < 0 || only == ncases + 16) run_conv("conv3x3 1x3x256 64->320 (ragged)", 1, 3, 256, 64, 0, 320, 1, 0, 256, false);
+    if (only < 0 || only == ncases + 17) run_conv("conv3x3 1x5x128 64->320 128-row", 1, 5, 128, 64, 0, 320, 1, 0, 128);
     // ... and three tiles per workgroup (8 workgroups, 24 tiles): the A ring's parity across tile boundaries for an odd and an
     // even number of A slabs per tile, next to the epilogue's staging area
     if (only == ncases + 13 || only == ncases + 14) {
