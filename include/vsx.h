@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 8
+#define VSX_ABI_VERSION 9
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -75,7 +75,14 @@ typedef struct vsx_gemm_desc {
     int64_t C1, C2;      /* a_mode 1: channels of A and A2 (C2 = 0 without A2); K = ks*ks*(C1+C2).  Multiples of 8;
                             with A2 both must be multiples of 64 (one K slab never straddles the two sources) */
     int64_t ks, stride;  /* a_mode 1: kernel size 1 or 3, stride 1 or 2 */
-    int64_t upsample;    /* a_mode 1: 1 = A/A2 are [.., H/2, W/2, C], read as nearest-2x upsampled */
+    int64_t upsample;    /* a_mode 1: 1 = A/A2 are [.., H/2, W/2, C], read as nearest-2x upsampled.
+                            ABI v9: 2 = the same convolution in its SUB-PIXEL form (Upsample3D, resnet.py:54,66): a 3x3 window on
+                            the upsampled image meets 2 x 2 source pixels, so output pixel (2i+ph, 2j+pw) is a 2x2-tap window on
+                            the source with the coinciding filter rows / columns added up.  B = FOUR [N, 9 C] matrices, class
+                            2 ph + pw first to last, whose taps (ph.., pw..) of a pad-1 3x3 window on the source hold the sums
+                            (videoswap_amd.ops.subpixel_weights); 4/9 of the multiplications.  ks 3, stride 1, one source with
+                            C1 % 64 == 0, bias only, N % 320 == 0, M/4 a multiple of 256 and a launch large enough for the
+                            persistent kernel — VSX_E_UNSUPPORTED otherwise (use upsample = 1). */
 
     /* B operand: [N (or 2N for geglu), K] row-major (PyTorch Linear weight / OHWI conv weight) */
     const void* B;

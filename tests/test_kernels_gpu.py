@@ -265,8 +265,13 @@ def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched, adden
     Wo = (2 * W if ups else W) // stride
     rowvec = rnd(nimg, Cout, seed=101) if addend == 'rowvec' else None
     res = rnd(nimg, Ho, Wo, Cout, seed=102) if addend == 'residual' else None
-    run = (lambda: ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec,
-                                rows_per_vec=Ho * Wo if rowvec is not None else 0, residual=res))
+    def run():      # (the nine-tap form of a nearest-2x convolution: its sub-pixel form has a test of its own below)
+        ops().CONV_SUBPIXEL = False
+        try:
+            return ops().conv2d(x, w, b, x2=x2, stride=stride, upsample=ups, rowvec=rowvec,
+                                rows_per_vec=Ho * Wo if rowvec is not None else 0, residual=res)
+        finally:
+            ops().CONV_SUBPIXEL = True
     # pp_sched bit 4: the tap-major K order, which sums like the tile kernels (bit for bit); the default order (the taps of a
     # 64-channel slab back to back: one fabric read of the input window instead of one per tap) is another fp32 summation order
     ops().set_option('pp_sched', _sched(sched) | 4)
@@ -291,6 +296,43 @@ def test_persistent_conv(nimg, H, W, C1, C2, Cout, ks, stride, ups, sched, adden
         assert torch.equal(old, same_order)
     else:
         assert rel_err(old, ref) < 2e-3
+
+
+@pytest.mark.parametrize('nimg,Hs,Ws,C,Cout', [
+    (32, 32, 32, 640, 640),        # Upsample3D 32 -> 64 at B = 2 (the 896-us launch of a forward)
+    (16, 16, 16, 1280, 1280),      # 16 -> 32 at B = 1
+    (16, 14, 24, 1280, 1280),      # the 448 x 768 clip's 14 x 24 -> 28 x 48 (W not a power of two)
+    (32, 8, 8, 1280, 1280),        # 8 -> 16: too few tiles for the persistent kernel, stays on the nine-tap form
+])
+def test_subpixel_form_of_the_nearest_2x_convolution(nimg, Hs, Ws, C, Cout):
+    """conv3x3(nearest_2x(x)) as four 2x2-tap convolutions of the source with the coinciding filter rows / columns added up
+    (vsx_gemm_desc.upsample = 2, ABI 9; ops.subpixel_weights): 4/9 of the multiplications, one launch, the epilogue scatters
+    every class to its pixels.  Against the fp32 reference, against the nine-tap kernel (the sums of fp16 filter taps are
+    rounded to fp16 once: the two differ by that rounding), and the combined weights against their definition."""
+    x = rnd(nimg, Hs, Ws, C, seed=160)
+    w, b = rnd(Cout, 3, 3, C, seed=161, scale=(9 * C) ** -0.5), rnd(Cout, seed=162)
+    o = ops()
+    w4 = o.subpixel_weights(w).float()
+    wf = w.float()
+    assert torch.equal(w4[0, :, 0, 0], wf[:, 0, 0].half().float())                                   # class (0, 0): the corner alone
+    assert torch.allclose(w4[0, :, 1, 1], wf[:, 1:, 1:].sum((1, 2)), atol=2e-3, rtol=2e-3)          # ... and the 2x2 block
+    assert torch.allclose(w4[3, :, 1, 1], wf[:, :2, :2].sum((1, 2)), atol=2e-3, rtol=2e-3)          # class (1, 1)
+    assert float(w4[0, :, 2].abs().max()) == 0 and float(w4[3, :, 0].abs().max()) == 0               # taps no class reads
+    eligible = o._subpixel_eligible(nimg, Hs, Ws, C, Cout, 3, 1, None, None, None, None)
+    assert eligible == (nimg * Hs * Ws >= 4096)
+    sub = o.conv2d(x, w, b, upsample=True)
+    o.CONV_SUBPIXEL = False
+    try:
+        nine = o.conv2d(x, w, b, upsample=True)
+    finally:
+        o.CONV_SUBPIXEL = True
+    ref = conv_ref(x, w, b, 1, None, True)
+    assert rel_err(sub, ref) < 2e-3
+    if eligible:
+        assert not torch.equal(sub, nine)
+        assert rel_err(sub, nine.float(), l2_tol=6e-4, row_tol=3e-3) < 4e-3
+    else:
+        assert torch.equal(sub, nine)
 
 
 @pytest.mark.parametrize('M,N,K,res', [(65536, 320, 320, True), (65536, 320, 320, False), (16384, 640, 640, True),

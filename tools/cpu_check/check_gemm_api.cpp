@@ -171,6 +171,61 @@ static void run_batched(const char* name, long b0, long b1, long M, long N, long
     report(name, vsx_gemm_f16(&d, nullptr), want, C);
 }
 
+// conv3x3(nearest_2x(x)) in its sub-pixel form (vsx_gemm_desc.upsample = 2): the four class matrices are built here the way
+// videoswap_amd.ops.subpixel_weights does, the expectation is the NINE-tap convolution of the upsampled image with the original
+// filter in double precision — the algebra, the descriptor handling and the scatter of the classes in one check.
+static void run_subpixel(const char* name, int nimg, int Hs, int Ws, int C, int Cout) {
+    const int H = 2 * Hs, W = 2 * Ws;
+    const long M = (long)nimg * H * W, K = 9L * C;
+    auto X = randh((size_t)nimg * Hs * Ws * C);
+    auto Wt = randh((size_t)Cout * K, 1.0f / sqrtf((float)K)), bias = randh(Cout);
+    std::vector<double> want((size_t)M * Cout);
+    for (int i = 0; i < nimg; ++i)
+        for (int ho = 0; ho < H; ++ho)
+            for (int wo = 0; wo < W; ++wo)
+                for (int co = 0; co < Cout; ++co) {
+                    double s = (double)bias[co];
+                    for (int kh = 0; kh < 3; ++kh)
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int h = ho - 1 + kh, w = wo - 1 + kw;
+                            if (h < 0 || h >= H || w < 0 || w >= W) continue;
+                            const half_t* wrow = Wt.data() + (size_t)co * K + (size_t)(kh * 3 + kw) * C;
+                            const size_t pix = ((size_t)i * Hs + h / 2) * Ws + w / 2;
+                            for (int c = 0; c < C; ++c) s += (double)X[pix * C + c] * (double)wrow[c];
+                        }
+                    want[((size_t)(i * H + ho) * W + wo) * Cout + co] = s;
+                }
+    // class 2 ph + pw: window tap (th, tw) of a pad-1 3x3 window on the source <- the filter taps that land on that source pixel
+    std::vector<half_t> W4((size_t)4 * Cout * K, (half_t)0.f);
+    const int taps[2][2][3] = {{{0, -1, -1}, {1, 2, -1}}, {{0, 1, -1}, {2, -1, -1}}};      // [parity][which of the two window taps] -> filter taps
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    for (int co = 0; co < Cout; ++co)
+                        for (int c = 0; c < C; ++c) {
+                            float s = 0.f;
+                            for (int fa = 0; fa < 3 && taps[ph][a][fa] >= 0; ++fa)
+                                for (int fb = 0; fb < 3 && taps[pw][b][fb] >= 0; ++fb)
+                                    s += (float)Wt[(size_t)co * K + (size_t)(taps[ph][a][fa] * 3 + taps[pw][b][fb]) * C + c];
+                            W4[((size_t)(2 * ph + pw) * Cout + co) * K + (size_t)((ph + a) * 3 + (pw + b)) * C + c] = (half_t)s;
+                        }
+    std::vector<half_t> Cm((size_t)M * Cout, (half_t)-7.f);
+    vsx_gemm_desc d{};
+    d.M = M; d.N = Cout; d.K = K; d.batch0 = d.batch1 = 1;
+    d.A = X.data(); d.a_mode = 1; d.H = H; d.W = W; d.C1 = C; d.ks = 3; d.stride = 1; d.upsample = 2;
+    d.B = W4.data(); d.ldb = K; d.C = Cm.data(); d.ldc = Cout; d.bias = bias.data();
+    d.alpha = 1.0; d.pad_lo = d.pad_hi = -1;
+    vsx_set_option("gemm_pp", 2);
+    const int rc = vsx_gemm_f16(&d, nullptr);
+    vsx_set_option("gemm_pp", 1);
+    report(name, rc, want, Cm);
+    d.upsample = 2;
+    const int rc2 = vsx_gemm_f16(&d, nullptr);          // too few tiles for the automatic choice: refused, not silently something else
+    printf("%-58s rc %d %s\n", "  ... refused where the persistent kernel would not run", rc2, rc2 == VSX_E_UNSUPPORTED ? "ok" : "FAIL");
+    if (rc2 != VSX_E_UNSUPPORTED) ++n_bad;
+}
+
 // 3x3 / 1x1 convolution with bias + time-embedding row vector + residual (both addends: the tile kernels)
 static std::vector<half_t> run_conv(const char* name, int nimg, int H, int W, int C1, int C2, int Cout, int ks, int stride, int ups, bool splitk,
                                     long pp = 1, bool both_addends = true) {
@@ -261,6 +316,7 @@ int main(int argc, char** argv) {
     if (only < 0 || only == nplain + 3) run_conv("conv3x3 1x12x8 72->96 /s2 (narrow tiles)", 1, 12, 8, 72, 0, 96, 3, 2, 0, false);
     if (only < 0 || only == nplain + 4) run_conv("conv1x1 2x8x8 128->320 nearest-2x", 2, 8, 8, 128, 0, 320, 1, 1, 1, false);
     if (only < 0 || only == nplain + 5) run_conv("conv3x3 split-K 1x8x8 192->320", 1, 8, 8, 192, 0, 320, 3, 1, 0, true);
+    if (only < 0 || only == nplain + 7) run_subpixel("sub-pixel nearest-2x conv 4x(16x16 -> 32x32) 64->320", 4, 16, 16, 64, 320);
     if (only < 0 || only == nplain + 6) {      // the persistent convolution through the entry point: bit for bit like the tile kernels
         rng_state = 7u;
         const auto a = run_conv("conv3x3 4x32x32 64->320 +rowvec, tile kernels", 4, 32, 32, 64, 0, 320, 3, 1, 0, false, 0, false);

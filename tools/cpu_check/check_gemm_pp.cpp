@@ -224,6 +224,66 @@ static void run_conv(const char* name, int nimg, int H, int W, int C1, int C2, i
     }
 }
 
+// Sub-pixel form of the nearest-2x convolution (upsample = 2): four classes of output pixels, each a 2x2-tap window on the
+// source with its own [N, 9 C] weight matrix (only the class's four taps are read); one GEMM over M = 4 Mc rows whose
+// epilogue scatters row (class, i, j) to pixel (2 i + ph, 2 j + pw).
+static void run_subpixel(const char* name, int nimg, int Hs, int Ws, int C, int Cout, int bm) {
+    using namespace vsxg;
+    const long Mc = (long)nimg * Hs * Ws, M = 4 * Mc, K9 = 9L * C;
+    auto X = randh((size_t)nimg * Hs * Ws * C);
+    auto Wt = randh((size_t)4 * Cout * K9, 1.0f / sqrtf((float)(4 * C))), bias = randh(Cout);
+    std::vector<double> want((size_t)M * Cout);
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        for (int im = 0; im < nimg; ++im)
+            for (int i = 0; i < Hs; ++i)
+                for (int j = 0; j < Ws; ++j)
+                    for (int co = 0; co < Cout; ++co) {
+                        double s = (double)bias[co];
+                        for (int kh = ph; kh < ph + 2; ++kh)
+                            for (int kw = pw; kw < pw + 2; ++kw) {
+                                const int h = i + kh - 1, w = j + kw - 1;
+                                if (h < 0 || h >= Hs || w < 0 || w >= Ws) continue;
+                                const half_t* wrow = Wt.data() + ((size_t)cls * Cout + co) * K9 + (size_t)(kh * 3 + kw) * C;
+                                const size_t pix = ((size_t)im * Hs + h) * Ws + w;
+                                for (int c = 0; c < C; ++c) s += (double)X[pix * C + c] * (double)wrow[c];
+                            }
+                        want[(((size_t)im * 2 * Hs + 2 * i + ph) * 2 * Ws + 2 * j + pw) * Cout + co] = s;
+                    }
+    }
+    std::vector<half_t> first;
+    for (long sched : {0L, 8L, 32L}) {
+        std::vector<half_t> C_((size_t)M * Cout, (half_t)-7.f);
+        GemmParams p{};
+        p.A = X.data(); p.B = Wt.data(); p.C = C_.data(); p.bias = bias.data();
+        p.M = M; p.N = Cout; p.K = 4L * C; p.ldb = K9; p.ldc = Cout; p.batch1 = 1; p.alpha = 1.0f;
+        p.a_mode = 1; p.H = Hs; p.W = Ws; p.C1 = C; p.C2 = 0; p.Ho = Hs; p.Wo = Ws; p.ks = 3; p.stride = 1; p.ups = 0; p.pad = 1;
+        p.vec4 = p.vec8 = 1; p.rows_per_vec = 1;
+        p.a_bytes = (unsigned)(X.size() * 2);
+        p.b_bytes = (unsigned)(Wt.size() * 2);
+        p.splitk = 1;
+        p.sp_Mc = (int)Mc;
+        if (!pp_supported(p) || Mc % bm) { printf("%s: not eligible\n", name); ++n_bad; return; }
+        g_sched = sched;
+        cpuhip_oob_reads = 0;
+        const int rc = launch_pp(p, bm, nullptr);
+        double num = 0, den = 0;
+        for (size_t i = 0; i < want.size(); ++i) {
+            const double d = (double)C_[i] - want[i];
+            num += d * d;
+            den += want[i] * want[i];
+        }
+        const double rel = sqrt(num / den);
+        bool same = true;
+        if (first.empty()) first = C_;
+        else same = memcmp(first.data(), C_.data(), C_.size() * sizeof(half_t)) == 0;
+        const bool ok = rc == 0 && rel < 3e-3 && same && cpuhip_oob_reads == 0;
+        printf("%-34s bm %3d sched %2ld: rc %d rel-L2 %.2e %s%s%s\n", name, bm, sched, rc, rel,
+               same ? "" : "DIFFERS from the first schedule ", cpuhip_oob_reads ? "reads past the tensor " : "", ok ? "ok" : "FAIL");
+        if (!ok) ++n_bad;
+    }
+}
+
 int main(int argc, char** argv) {
     const Case cases[] = {
         {"plain 256x320x64", 256, 320, 64, false, false, 256},                 // one tile, one slab
@@ -271,6 +331,10 @@ int main(int argc, char** argv) {
     if (only < 0 || only == ncases + 15) run_conv("conv3x3 1x4x128 64->320", 1, 4, 128, 64, 0, 320, 1, 0, 256);
     if (only < 0 || only == ncases + 16) run_conv("conv3x3 1x3x256 64->320 (ragged)", 1, 3, 256, 64, 0, 320, 1, 0, 256, false);
     if (only < 0 || only == ncases + 17) run_conv("conv3x3 1x5x128 64->320 128-row", 1, 5, 128, 64, 0, 320, 1, 0, 128);
+    // sub-pixel form of the nearest-2x convolution: 2 tiles per class (8 x 32 source), two channel slabs; one 128-row tile per class
+    if (only < 0 || only == ncases + 18) run_subpixel("subpixel 2x8x32 128->320", 2, 8, 32, 128, 320, 256);
+    if (only < 0 || only == ncases + 19) run_subpixel("subpixel 1x8x16 64->320 128-row", 1, 8, 16, 64, 320, 128);
+    if (only < 0 || only == ncases + 20) run_subpixel("subpixel 1x14x24 64->640 (W = 24), 128-row", 2, 8, 24, 64, 640, 128);
     // ... and three tiles per workgroup (8 workgroups, 24 tiles): the A ring's parity across tile boundaries for an odd and an
     // even number of A slabs per tile, next to the epilogue's staging area
     if (only == ncases + 13 || only == ncases + 14) {

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.environ.get('VSX_LIB_VARIANT') or None
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so' if not VARIANT else f'libvsx_{VARIANT}.so')
 
-VSX_ABI_VERSION = 8
+VSX_ABI_VERSION = 9
 
 
 class VsxError(RuntimeError):

@@ -1061,6 +1061,19 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
         VSX_REQUIRE(!d->upsample || (d->H % 2 == 0 && d->W % 2 == 0), VSX_E_BADSHAPE, "gemm: upsample needs even H/W");
         p.H = (int)d->H; p.W = (int)d->W; p.C1 = (int)d->C1; p.C2 = (int)d->C2;
         p.ks = (int)d->ks; p.stride = (int)d->stride; p.ups = d->upsample ? 1 : 0;
+        const bool subpix = d->upsample == 2;
+        if (subpix) {
+            // sub-pixel form (vsx.h: upsample = 2): internally a plain 3x3 window on the SOURCE image, four taps per class
+            VSX_REQUIRE(d->ks == 3 && d->stride == 1 && d->C2 == 0 && d->C1 % 64 == 0 && d->pad_lo < 0 && d->pad_hi < 0 &&
+                            !d->rowvec && !d->residual && !d->geglu && d->c_mode == 0 && !d->rowscale && !d->rowstats,
+                        VSX_E_UNSUPPORTED, "gemm: the sub-pixel form takes a single-source 3x3 stride-1 convolution with a bias only");
+            VSX_REQUIRE(d->M % 4 == 0, VSX_E_BADSHAPE, "gemm: sub-pixel form: M must be a multiple of 4");
+            p.ups = 0;
+            p.H = (int)d->H / 2;
+            p.W = (int)d->W / 2;
+            p.sp_Mc = (int)(d->M / 4);
+            p.K = 4 * d->C1;                 // slabs actually multiplied (the weight rows stay 9 C long: ldb)
+        }
         const bool sym = d->pad_lo < 0 && d->pad_hi < 0;
         VSX_REQUIRE(sym || (d->pad_lo >= 0 && d->pad_hi >= 0 && d->pad_lo < d->ks && d->pad_hi < d->ks), VSX_E_BADSHAPE,
                     "gemm: conv padding (%ld, %ld) for kernel size %ld", (long)d->pad_lo, (long)d->pad_hi, (long)d->ks);
@@ -1069,7 +1082,7 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
         p.Ho = (p.H + pad_lo + pad_hi - p.ks) / p.stride + 1;
         p.Wo = (p.W + pad_lo + pad_hi - p.ks) / p.stride + 1;
         {
-            const long pix = (d->M / ((long)p.Ho * p.Wo)) * (long)(p.ups ? p.H / 2 : p.H) * (p.ups ? p.W / 2 : p.W);
+            const long pix = (d->M / ((long)p.Ho * p.Wo) / (subpix ? 4 : 1)) * (long)(p.ups ? p.H / 2 : p.H) * (p.ups ? p.W / 2 : p.W);
             VSX_REQUIRE(pix * d->C1 * 2 < (1L << 31) && pix * d->C2 * 2 < (1L << 31), VSX_E_UNSUPPORTED,
                         "gemm: conv source tensors must be smaller than 2 GiB");
             p.a_bytes = (unsigned)(pix * d->C1 * 2);
@@ -1077,6 +1090,11 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
         }
         VSX_REQUIRE(d->M % ((long)p.Ho * p.Wo) == 0, VSX_E_BADSHAPE, "gemm: conv M (%ld) not a multiple of Ho*Wo (%d*%d)",
                     (long)d->M, p.Ho, p.Wo);
+        if (subpix) {                        // B = four [N, 9 C] matrices, one per (ph, pw) class
+            const long bb = ((4 * d->N - 1) * d->ldb + d->K) * 2;
+            VSX_REQUIRE(bb < (1L << 31), VSX_E_UNSUPPORTED, "gemm: B operand slice must be smaller than 2 GiB");
+            p.b_bytes = (unsigned)bb;
+        }
     } else {
         return vsx_fail(VSX_E_UNSUPPORTED, "gemm: a_mode %d", p.a_mode);
     }
@@ -1148,6 +1166,9 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
         p.rowstats = (float*)d->rowstats;
         p.rowstats_parts = (int)stat_parts;
     }
+    if (p.sp_Mc > 0)
+        VSX_REQUIRE((pp256 && p.sp_Mc % 256 == 0) || (pp128 && p.sp_Mc % 128 == 0), VSX_E_UNSUPPORTED,
+                    "gemm: the sub-pixel form runs on the persistent kernel only (enough tiles, rows per class a multiple of the tile)");
     if (pp256) {
         rc = launch_pp(p, 256, stream);
     } else if (pp128) {
@@ -1198,7 +1219,7 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
     if (sample) {
         (void)hipEventRecord(e1, stream);
         g_prof.n += 1;
-        g_prof.flop += 2.0 * (double)d->M * (double)cols * (double)d->K * (double)nbatch;
+        g_prof.flop += 2.0 * (double)d->M * (double)cols * (double)p.K * (double)nbatch;      // (sub-pixel form: the 4 C it multiplies)
     }
     return rc;
 }

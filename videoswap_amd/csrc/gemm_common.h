@@ -34,6 +34,7 @@ struct GemmParams {
     float alpha;
     int tiles_total;                       // persistent kernel: number of output tiles
     int pp_flags;                          // persistent kernel: PP_* option bits (tile walk)
+    int sp_Mc;                             // sub-pixel form of the nearest-2x convolution (upsample = 2): GEMM rows per (ph, pw) class, else 0
 };
 
 // pp_flags: option bits of "pp_sched" / VSX_PP_SCHED.  Round 3 measured five candidates on the GPU

@@ -140,7 +140,9 @@ __device__ __forceinline__ void pre_fetch(const PreSrc& ps, const int lane, cons
 // identity, bias, row vector | residual).
 // STATS: the pass also writes (sum, sum of squares) of its row's ROUNDED outputs over the chunk's columns into
 // p->rowstats[m][part] (vsx.h, ABI 8): the LPR lanes that share a row add up with log2(LPR) cross-lane steps.
-template <int CW, int PD, bool LN, bool STATS = false>   // CW: chunk width in output columns: 64, 32 or 16; PD: ring depth (0: no addend)
+// SUBPIX (sub-pixel form of the nearest-2x convolution, gemm_pp_kernel CONV = 3): GEMM row m = class * Mc + r is the output
+// pixel (2 i + ph, 2 j + pw) of source pixel r = (image row i', j): output row 4 Ws i' + 2 Ws ph + 2 j + pw.
+template <int CW, int PD, bool LN, bool STATS = false, bool SUBPIX = false>   // CW: chunk width in output columns: 64, 32 or 16; PD: ring depth (0: no addend)
 __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, const int lane, const int mblk,
                                               const int ncol, const float* cst, const PreSrc& ps, h8* pre,
                                               const int fbase, const int nf, const float st_rs = 1.f,
@@ -190,7 +192,13 @@ __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, con
         h8 pk;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pk[e] = (half_t)o[e];
-        if (m < Mi) *reinterpret_cast<h8*>(cp + ((unsigned)m * ldc + (unsigned)n)) = pk;
+        if constexpr (SUBPIX) {
+            const unsigned Mc = (unsigned)p->sp_Mc, Ws = (unsigned)p->Wo;
+            const unsigned cls = (unsigned)m / Mc, r = (unsigned)m - cls * Mc;
+            const unsigned q = r / Ws, j = r - q * Ws;
+            const unsigned orow = 4u * Ws * q + 2u * j + 2u * Ws * (cls >> 1) + (cls & 1u);
+            if (m < Mi) *reinterpret_cast<h8*>(cp + (orow * ldc + (unsigned)n)) = pk;
+        } else if (m < Mi) *reinterpret_cast<h8*>(cp + ((unsigned)m * ldc + (unsigned)n)) = pk;
         if constexpr (STATS) {
             // v_dot2_f32_f16 on the packed pairs: sum and sum of squares of the rounded values without converting them back
             // (8 instructions per pass instead of 24; fp16 x fp16 products are exact in fp32)
@@ -221,7 +229,7 @@ constexpr int EPI_LN = 2;           // LayerNorm folded into the GEMM (rowscale 
 constexpr int EPI_GEGLU = 4;        // h * gelu(g)
 constexpr int EPI_STATS = 8;        // row statistics of the output for a LayerNorm that follows (not with LN / GEGLU)
 
-template <int TM, int EPI, int PD>
+template <int TM, int EPI, int PD, bool SUBPIX = false>
 __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, const int mrow0, const int ncol0,
                                             const int gcol0, const int lane) {
     constexpr bool ADD = (EPI & EPI_ADD) != 0, LN = (EPI & EPI_LN) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
@@ -363,8 +371,8 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
                 if (i == 0 && c == 0) park_constants();
                 __builtin_amdgcn_sched_barrier(0);
                 const float* cc_ = use_cst ? cst + c * 64 : nullptr;
-                if (c < 2) epilogue_rows<64, ADD ? PD : 0, LN, STATS>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + c * 4, NF, st_rs[i], st_rt[i], part0 + c);
-                else epilogue_rows<32, ADD ? PD : 0, LN, STATS>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + 8, NF, st_rs[i], st_rt[i], part0 + c);
+                if (c < 2) epilogue_rows<64, ADD ? PD : 0, LN, STATS, SUBPIX>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + c * 4, NF, st_rs[i], st_rt[i], part0 + c);
+                else epilogue_rows<32, ADD ? PD : 0, LN, STATS, SUBPIX>(p, stg, lane, mblk, ncol0 + j0 * 32, cc_, ps, pre, i * 10 + 8, NF, st_rs[i], st_rt[i], part0 + c);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     bool need_setup = true;
     int t_kh = 0, t_kw = 0, t_c = 0;             // conv: filter tap / channel base of the next slab
     bool t_second = false, t_dirty = true, t_src_dirty = true;
-    const bool tap_inner = CONV == 2 || (CONV && (flags & PP_CONV_TAP_MAJOR) == 0);
+    const bool tap_inner = CONV >= 2 || (CONV && (flags & PP_CONV_TAP_MAJOR) == 0);
     // SHARED A SLAB (stride-1 3x3, W a power of two in [32, BM]; launch_pp decides).  The windows of the taps (kh, 0..2) are
     // one-pixel shifts of each other, and a tile starts at the first pixel of an image row: the A slab of tap (kh, 1) is
     // streamed ONCE per (channel slab, kh) and the MFMAs of kw = 0 / 2 read their fragments one LDS row lower / higher; the
@@ -482,6 +490,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     // tile's operands; k + 1 never shares a slot with k, nor the next tile's k = 0 with this tile's last (nk / 3 - 1 and nk
     // differ in parity for every nk = 3q).
     constexpr bool ashift = CONV == 2;
+    // SUB-PIXEL FORM of the nearest-2x convolution (CONV = 3; Upsample3D, resnet.py:54,66).  A 3x3 window on the upsampled image
+    // meets only 2 x 2 source pixels: output pixel (2 i + ph, 2 j + pw) reads source rows i - 1 + ph, i + ph with the filter rows
+    // {0} | {1, 2} (ph = 0) or {0, 1} | {2} (ph = 1) added up, and the same along the columns.  The host adds the taps up once
+    // (B = four [N, 9 C] matrices, one per (ph, pw) class, whose taps (ph.., pw..) hold the sums), and the launch runs the four
+    // classes as one GEMM over M = 4 Mc rows: a tile belongs to one class (Mc a multiple of the tile height), walks the class's
+    // four taps of a PLAIN 3x3 window on the source — 4 / 9 of the slabs — and its epilogue scatters the rows to their pixels.
+    constexpr bool subpix = CONV == 3;
+    int sp_kh0 = 0, sp_kw0 = 0;
     const int wmask = ashift ? p->W - 1 : 0;
     int i_aslot = 0, i_sbA = 0;
     bool i_hasA = true;
@@ -494,6 +510,14 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         tile_coords(tile, tiles_n, tiles_m, blocked, tile_m, tile_n);
         i_m0 = tile_m * BM;
         i_rowB = (unsigned)(geglu ? tile_n * (BN / 2) : tile_n * BN) * ldb2;
+        int sp_m0 = 0;                          // first GEMM row of the tile's class
+        if constexpr (subpix) {
+            const int cls = i_m0 / p->sp_Mc;
+            sp_m0 = cls * p->sp_Mc;
+            sp_kh0 = cls >> 1;
+            sp_kw0 = cls & 1;
+            i_rowB += (unsigned)(cls * (int)p->N) * ldb2;
+        }
         if constexpr (CONV) {
             const unsigned Wo = (unsigned)p->Wo, hw = (unsigned)p->Ho * Wo;
             const int stride = p->stride, pad = p->pad, ks = p->ks, ups = p->ups;
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             const int Hs = ups ? (H >> 1) : H, Ws = ups ? (W >> 1) : W;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
-                const int m = i_m0 + a_piece(i) * 8 + lrow;
+                const int m = i_m0 + a_piece(i) * 8 + lrow - (subpix ? sp_m0 : 0);      // (sub-pixel form: the row inside its class)
                 const unsigned mm = m < Mi ? (unsigned)m : 0u;
                 const unsigned img = mm / hw;
                 const unsigned rem = mm - img * hw;
@@ -518,7 +542,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
                 a_mk[i] = mk | ((h0 & 1) << 9) | ((w0 & 1) << 10);
                 a_px[i] = ((int)img * Hs + (ups ? (h0 >> 1) : h0)) * Ws + (ups ? (w0 >> 1) : w0);
             }
-            t_kh = 0; t_kw = 0; t_c = 0; t_second = false; t_dirty = true;
+            t_kh = subpix ? sp_kh0 : 0; t_kw = subpix ? sp_kw0 : 0; t_c = 0; t_second = false; t_dirty = true;
             t_src_dirty = true;
             i_aslot = (i_g & 1) ^ 1;            // the tile's first slab toggles it to the slot of its B slab
         }
@@ -565,10 +589,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
                 // taps after the first hit L2 (tap-major order re-reads the input from the fabric once per tap: 3.8 - 7.7 x the
                 // algorithmic bytes on the convolutions, profiles/r03_gemm_traffic_by_shape.txt)
                 t_dirty = true;
-                if (++t_kw == ks) {
-                    t_kw = 0;
-                    if (++t_kh == ks) {
-                        t_kh = 0;
+                if (++t_kw == (subpix ? sp_kw0 + 2 : ks)) {
+                    t_kw = subpix ? sp_kw0 : 0;
+                    if (++t_kh == (subpix ? sp_kh0 + 2 : ks)) {
+                        t_kh = subpix ? sp_kh0 : 0;
                         t_c += BK;
                         if (t_c >= csz) { t_c = 0; t_second = true; t_src_dirty = true; }      // (past source 2: the tile is done)
                     }
@@ -781,7 +805,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             const int stg_off = wave < NFIT ? ((c_g - 1) & 1) * STAGE + wave * EP_BYTES
                                             : 2 * STAGE + (wave - NFIT) * EP_BYTES;
             constexpr int PD = (EPI & EPI_LN) ? 2 : ((CONV || (EPI & EPI_STATS)) ? 3 : 4);      // addend ring depth (what fits without scratch)
-            epilogue_pp<TM, EPI, PD>(acc, reinterpret_cast<float*>(smem + stg_off), tile_m * BM + wr * WM, n0 + wc * WN,
+            epilogue_pp<TM, EPI, PD, CONV == 3>(acc, reinterpret_cast<float*>(smem + stg_off), tile_m * BM + wr * WM, n0 + wc * WN,
                                  n0 + wc * TN * 16, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -867,11 +891,13 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     if (conv && (p.pp_flags & (PP_CONV_TAP_MAJOR | PP_CONV_PRIVATE_A)) == 0 && p.ks == 3 && p.stride == 1 && p.ups == 0 &&
         p.pad == 1 && p.Wo == p.W && p.Ho == p.H && p.W >= 32 && p.W <= bm && (p.W & (p.W - 1)) == 0)
         p.pp_flags |= PP_CONV_ASHIFT_ON, conv = 2;
+    if (conv && p.sp_Mc > 0) conv = 3;
     const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0) |
                     (p.rowstats ? EPI_STATS : 0);
 #define VSX_PP_CASE(TM_, CONV_, EPI_) \
     if ((bm == 256) == (TM_ == 2) && conv == CONV_ && epi == (EPI_)) return launch_one<TM_, CONV_, (EPI_)>(p, stream);
 #define VSX_PP_CASES(TM_)                             \
+    VSX_PP_CASE(TM_, 3, 0)                        \
     VSX_PP_CASE(TM_, 2, 0)                        \
     VSX_PP_CASE(TM_, 2, EPI_ADD)                  \
     VSX_PP_CASE(TM_, 1, 0)                        \

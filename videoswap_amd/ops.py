@@ -69,7 +69,8 @@ if os.environ.get('VSX_GEMM_LOG'):
     _gemm_log = open(os.environ['VSX_GEMM_LOG'], 'w')
 
 
-def gemm(desc):
+def gemm(desc, k_flop=None):
+    """k_flop: the K the launch actually multiplies when that is not desc.K (sub-pixel form of the nearest-2x convolution)"""
     if _gemm_log is not None:
         _gemm_log.write(f'{desc.M} {desc.N} {desc.K} {desc.batch0 * desc.batch1} {desc.a_mode} {desc.ks} {desc.stride} '
                         f'{desc.upsample} {desc.C1} {desc.C2} {desc.H} {desc.W} {desc.geglu} {desc.c_mode} '
@@ -77,7 +78,7 @@ def gemm(desc):
         _gemm_log.flush()
     if FlopCounter.enabled:
         cols = desc.N * (2 if desc.geglu else 1)
-        FlopCounter.gemm += 2.0 * desc.M * cols * desc.K * desc.batch0 * desc.batch1
+        FlopCounter.gemm += 2.0 * desc.M * cols * (desc.K if k_flop is None else k_flop) * desc.batch0 * desc.batch1
     lib = _lib.load()
     need = lib.vsx_gemm_workspace(ctypes.byref(desc)) if (desc.M <= 20480 and desc.K >= 768) else 0
     stream = _stream()
@@ -183,6 +184,7 @@ def fold_cache_tensors():
     for hit in _fold_cache.values():
         out.extend((hit[2], hit[3], hit[4]))
         out.extend(hit[5].values())
+    out.extend(hit[2] for hit in _subpixel_cache.values())
     return out
 
 
@@ -335,6 +337,54 @@ def linear_vt(x, weight, bias, rows_per_img, ldvt=None):
     return vt
 
 
+# VSX_CONV_SUBPIXEL=0: the nearest-2x convolutions always as nine taps on the upsampled image (A/B runs)
+CONV_SUBPIXEL = os.environ.get('VSX_CONV_SUBPIXEL', '1') != '0'
+_subpixel_cache = {}      # id(weight) -> (stamp, weight ref, [4, Cout, 3, 3, C] fp16)
+
+
+def subpixel_weights(weight):
+    """Sub-pixel form of `conv3x3(nearest_2x(x))` (Upsample3D, resnet.py:54,66): a 3x3 window on the upsampled image meets
+    only 2 x 2 source pixels, so output pixel (2 i + ph, 2 j + pw) is a 2 x 2-tap convolution of the SOURCE with the filter
+    rows / columns that land on the same source pixel added up (fp32 sums, rounded to fp16 once):
+        ph = 0: source rows (i - 1, i) <- filter rows ({0}, {1, 2});   ph = 1: source rows (i, i + 1) <- ({0, 1}, {2})
+    and the same along the columns.  Returns [4, Cout, 3, 3, C] (class = 2 ph + pw): the four taps of class (ph, pw) sit at
+    window positions (ph.., pw..) of a plain pad-1 3x3 window on the source, the other five are zero and never read
+    (include/vsx.h: vsx_gemm_desc.upsample = 2).  4 / 9 of the multiplications of the nine-tap form.  Cached per weight."""
+    import weakref
+    key = id(weight)
+    stamp = (weight.data_ptr(), weight._version)
+    hit = _subpixel_cache.get(key)
+    if hit is None or hit[0] != stamp or hit[1]() is not weight:
+        with torch.no_grad():
+            w = weight.detach().float()                                   # [Cout, 3, 3, C]
+            rows = {0: ((0, (0,)), (1, (1, 2))), 1: ((1, (0, 1)), (2, (2,)))}      # parity -> ((window tap, filter taps), ...)
+            out = torch.zeros(4, *w.shape, dtype=torch.float32, device=w.device)
+            for ph in (0, 1):
+                for pw in (0, 1):
+                    for th, fh in rows[ph]:
+                        for tw, fw in rows[pw]:
+                            out[2 * ph + pw, :, th, tw] = sum(w[:, a, b] for a in fh for b in fw)
+            out = out.to(_F16).contiguous()
+        fresh = hit is None or hit[1]() is not weight
+        hit = (stamp, weakref.ref(weight), out)
+        _subpixel_cache[key] = hit
+        if fresh:
+            weakref.finalize(weight, _subpixel_cache.pop, key, None)
+    return hit[2]
+
+
+def _subpixel_eligible(nimg, Hs, Ws, C1, Cout, ks, stride, x2, rowvec, residual, padding):
+    """Mirrors the library's own conditions (gemm.hip: upsample == 2): bias-only single-source 3x3, and a launch the
+    persistent kernel's 256-row tiles take (enough tiles, whole tiles per class)."""
+    if not CONV_SUBPIXEL or ks != 3 or stride != 1 or x2 is not None or rowvec is not None or residual is not None \
+            or padding is not None or C1 % 64 or Cout % 320:
+        return False
+    if _options.get('gemm_pp', 1) not in (1, 2) or (_options.get('tile_tune', 0) & 15):
+        return False                    # the persistent kernel is switched off / a tile is forced (A/B runs, tests)
+    mc = nimg * Hs * Ws
+    return mc % 256 == 0 and (4 * mc // 256) * (Cout // 320) >= 192
+
+
 def conv2d(x, weight, bias=None, *, x2=None, stride=1, upsample=False, rowvec=None, rows_per_vec=0,
            residual=None, padding=None):
     """Channels-last conv as implicit GEMM.
@@ -368,6 +418,13 @@ def conv2d(x, weight, bias=None, *, x2=None, stride=1, upsample=False, rowvec=No
     d.B = weight.data_ptr(); d.ldb = d.K
     d.C = out.data_ptr(); d.ldc = Cout
     d.bias = bias.data_ptr() if bias is not None else None
+    if upsample and _subpixel_eligible(nimg, Hs, Ws, C1, Cout, ks, stride, x2, rowvec, residual, padding):
+        w4 = subpixel_weights(weight)
+        d.upsample = 2
+        d.B = w4.data_ptr()
+        d.alpha = 1.0
+        gemm(d, k_flop=4 * C1)
+        return out
     if rowvec is not None:
         d.rowvec = rowvec.data_ptr(); d.rows_per_vec = rows_per_vec
     if residual is not None:
@@ -663,9 +720,14 @@ def adapter_scatter(tracks, selected, feat, h, w, rate, out_scale=1.0):
     return out
 
 
+_options = {'gemm_pp': int(os.environ.get('VSX_GEMM_PP', '1')), 'tile_tune': int(os.environ.get('VSX_TUNE_TILE', '0'))}
+
+
 def set_option(name, value):
-    """Process-wide tuning / test switch of libvsx (see include/vsx.h: "gemm_pp", "pp_sched")."""
+    """Process-wide tuning / test switch of libvsx (see include/vsx.h: "gemm_pp", "pp_sched", "tile_tune").  The values are
+    mirrored here for the host-side choices that depend on them (`_subpixel_eligible`)."""
     check(_lib.load().vsx_set_option(name.encode(), int(value)), 'vsx_set_option')
+    _options[name] = int(value)
 
 
 _prof_state = {'on': 0, 'max': 0, 'stride': 1, 'paused': False}
