@@ -59,10 +59,12 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
             ('15', '0'),                         # 3x3 convolution, two sources, row-vector ring
             ('19', '0'),                         # 48 rows per vector: 32-row blocks that meet two row vectors
             ('21', '0'),                         # convolution without an addend, 128-row tiles
-            ('23', '0,16,32'),                   # image rows of 32 pixels, two sources: ONE A slab per filter row read at three
-                                                 # row offsets (default) = a private slab per tap (16), bit for bit; 32 = every
-                                                 # CU walks the pieces of a slab in the same order
-            ('31', '0,16')]                      # ... image rows as long as the tile, ragged last tile
+            ('22', '0,16,32'),                   # image rows of 32 pixels: ONE A slab per filter row read at three row offsets
+                                                 # (default) = a private slab per tap (16), bit for bit; 32 = every CU walks the
+                                                 # pieces of a slab in the same order
+            ('34', '0')]                         # sub-pixel form of the nearest-2x convolution: four classes of output pixels
+    if os.environ.get('VSX_CPU_CHECK_FULL'):     # a minute or more each: two sources, image rows as long as the tile, W = 24
+        runs += [('23', '0,16,32'), ('31', '0,16'), ('33', '0,8'), ('35', '0')]
     # (`make -C tools/cpu_check run` walks every case: the remaining kernel kinds, stride 2, nearest-2x, K tails)
     for case, scheds in runs:
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900)
@@ -92,7 +94,9 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     env = {k: v for k, v in os.environ.items() if k not in ('VSX_TUNE_TILE', 'VSX_GEMM_PP', 'VSX_PP_SCHED')}
-    for case in [str(c) for c in range(13)] + ['14', '15', '16', '17', '18']:      # (13: the persistent kernel, covered above)
+    # (13: the persistent kernel, covered above; 20: the nearest-2x convolution in its sub-pixel form against the nine-tap
+    # convolution of the upsampled image, and the refusal where the persistent kernel would not run)
+    for case in [str(c) for c in range(13)] + ['14', '15', '16', '17', '18', '20']:
         r = subprocess.run([exe, case], capture_output=True, text=True, timeout=600, env=env)
         print(r.stdout)
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
