@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 4: shared A slab (default) / private A slab (16) x common B piece order / per-CU rotation (32), one process
+# (record: build of e46953b's working tree, where bit 32 = B piece rotation ON and 16 = private A slab; today bit 32 = common order)
 TAG=${1:-r04k}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4: piece rotation, position-balanced (the variant order rotates round by round): B rotation on (default) / off (32),
 # A rotation (64), under the product's dispatch, B = 2
+# (record: in the build of that call s0 = B rotation only, 32 = none, 64 = A + B, 96 = A only; 6701f83 shipped A everywhere + B in the plain GEMMs)
 TAG=${1:-r04m}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out

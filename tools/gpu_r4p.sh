@@ -1,5 +1,6 @@
 #!/bin/bash
 # Round 4: flash attention, key-tile rotation per 256-query block (option attn_rot) against the common sweep order
+# (record: option attn_rot existed only in the build of that call; removed again in 4478709 — no effect)
 TAG=${1:-r04p}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
