@@ -1,0 +1,107 @@
+"""How much accuracy would Winograd F(2x2, 3x3) cost the 3x3 stride-1 convolutions under fp16 operands and fp32 accumulation?
+CPU emulation: the transformed filters U = G g G^T and the transformed input tiles V = B^T d B are computed in
+fp32 and ROUNDED TO FP16 (what the MFMA would read), the 16 element-wise GEMMs accumulate in fp32, the output transform
+Y = A^T M A runs in fp32 and the result is rounded to fp16 — against the direct convolution with fp16 operands, fp32 accumulation
+and an fp16 result (what the implicit-GEMM kernels compute), both measured against a float64 convolution of the same fp16 inputs.
+
+    python tools/winograd_error_probe.py            # a few seconds per case on the CPU
+"""
+import torch
+import torch.nn.functional as F
+
+G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64)
+BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float64)
+
+
+def h(x):
+    """round to fp16 and come back (the storage format of an MFMA operand)"""
+    return x.to(torch.float16).to(x.dtype)
+
+
+def winograd(x, w, round_operands=True):
+    """x [N, C, H, W] (H, W even), w [O, C, 3, 3], zero padding 1 -> [N, O, H, W]"""
+    n, c, hh, ww = x.shape
+    o = w.shape[0]
+    u = torch.einsum('ij,ocjk,lk->ocil', G.float(), w.float(), G.float())              # [O, C, 4, 4]
+    xp = F.pad(x.float(), (1, 1, 1, 1))
+    tiles = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                          # [N, C, H/2, W/2, 4, 4]
+    v = torch.einsum('ij,nctsjk,lk->nctsil', BT.float(), tiles, BT.float())             # [N, C, th, tw, 4, 4]
+    if round_operands:
+        u, v = h(u), h(v)
+    m = torch.einsum('ocil,nctsil->notsil', u, v)                                       # fp32 accumulation over c
+    y = torch.einsum('ij,notsjk,lk->notsil', AT.float(), m, AT.float())                 # [N, O, th, tw, 2, 2]
+    return y.permute(0, 1, 2, 4, 3, 5).reshape(n, o, hh, ww)
+
+
+def case(name, c, o, hw, act):
+    g = torch.Generator().manual_seed(0)
+    x = act(torch.randn(2, c, hw, hw, generator=g))
+    w = torch.randn(o, c, 3, 3, generator=g) * (9 * c) ** -0.5
+    x, w = h(x), h(w)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    direct = h(F.conv2d(x, w, padding=1))                       # fp16 operands, fp32 accumulation, fp16 result
+    wino = h(winograd(x, w))
+    wino_exact_ops = h(winograd(x, w, round_operands=False))
+    err = lambda y: float((y.double() - ref).norm() / ref.norm())      # noqa: E731
+    print(f'{name:46s} direct {err(direct):.2e}   Winograd, fp16 U and V {err(wino):.2e} ({err(wino) / err(direct):.1f} x)   '
+          f'Winograd, fp32 U and V {err(wino_exact_ops):.2e}')
+
+
+if __name__ == '__main__':
+    silu = F.silu
+    case('C = 320, 32 x 32, unit-variance input', 320, 320, 32, lambda t: t)
+    case('C = 320, 32 x 32, SiLU(GroupNorm-like) input', 320, 320, 32, silu)
+    case('C = 640, 16 x 16, SiLU input', 640, 640, 16, silu)
+    case('C = 320, input with a large per-channel offset', 320, 320, 32, lambda t: silu(t) + 3.0 * torch.randn(1, 320, 1, 1))
+
+
+def unet_probe(frames=2, latent=32):
+    """The same question through the whole UNet (SD-1.5 width, seeded synthetic weights of the parity tests, fp32 oracle on the
+    CPU): every 3x3 stride-1 convolution is replaced by (b) its direct form with fp16 operands and an fp16 result — the numerics
+    of the implicit-GEMM kernels — or (c) Winograd F(2x2, 3x3) with fp16 U and V; everything else stays fp32.  The two errors
+    against the untouched fp32 forward say what the convolutions alone contribute in either form."""
+    import os
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import unet3d
+    from videoswap_amd.synthetic import synth_weights_
+    torch.manual_seed(0)
+    model = synth_weights_(unet3d.AnimateDiffUNet3DModel(**unet3d.full_config()), seed=1234).float().eval()
+    x = torch.randn(1, 4, frames, latent, latent)
+    txt = torch.randn(1, 77, 768)
+    orig = torch.nn.Conv2d._conv_forward
+    mode = {'kind': None, 'n': 0}
+
+    def patched(self, inp, weight, bias):
+        if mode['kind'] and weight.shape[2:] == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) \
+                and inp.shape[2] % 2 == 0 and inp.shape[3] % 2 == 0:
+            mode['n'] += 1
+            xi, wi = h(inp), h(weight)
+            y = F.conv2d(xi, wi, None, padding=1) if mode['kind'] == 'direct' else winograd(xi, wi)
+            if bias is not None:
+                y = y + bias[None, :, None, None]
+            return h(y)
+        return orig(self, inp, weight, bias)
+
+    torch.nn.Conv2d._conv_forward = patched
+    outs = {}
+    try:
+        with torch.no_grad():
+            for kind in (None, 'direct', 'winograd'):
+                mode['kind'], mode['n'] = kind, 0
+                t0 = time.time()
+                o = model(x, torch.tensor(481), txt)
+                outs[kind] = (o.sample if hasattr(o, 'sample') else o[0]).double()
+                print(f'# forward ({kind or "fp32"}): {time.time() - t0:.1f} s, {mode["n"]} convolutions replaced', flush=True)
+    finally:
+        torch.nn.Conv2d._conv_forward = orig
+    ref = outs[None]
+    for kind in ('direct', 'winograd'):
+        print(f'UNet forward T = {frames}, {latent} x {latent}: 3x3 stride-1 convolutions as {kind:9s}: rel-L2 against fp32 '
+              f'{float((outs[kind] - ref).norm() / ref.norm()):.2e}')
+
+
+if __name__ == '__main__':
+    unet_probe()
