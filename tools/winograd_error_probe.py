@@ -5,6 +5,9 @@ Y = A^T M A runs in fp32 and the result is rounded to fp16 — against the direc
 and an fp16 result (what the implicit-GEMM kernels compute), both measured against a float64 convolution of the same fp16 inputs.
 
     python tools/winograd_error_probe.py            # a few seconds per case on the CPU
+
+Result (round 4): one convolution 2.1e-4 -> 5.1e-4; the UNet forward's convolution share 7.7e-4 -> 1.2e-3 — admissible under the
+parity rule.  The mapping onto the persistent kernel is what rules Winograd out here: 16 live accumulator tiles.
 """
 import torch
 import torch.nn.functional as F
