@@ -49,14 +49,17 @@ def round_up(x, m):
 # GEMM family
 # --------------------------------------------------------------------------------------------
 class FlopCounter:
-    """Algorithmic FLOP (2 x MAC, true dimensions, no padding) of the MFMA kernels launched while enabled."""
+    """Algorithmic FLOP (2 x MAC, true dimensions, no padding) of the MFMA kernels launched while enabled.  `gemm` counts what
+    the launches multiply; `gemm_saved` what the reference's formulation would have multiplied on top of that (the five taps
+    per output pixel that the sub-pixel form of the nearest-2x convolutions never computes)."""
     enabled = False
     gemm = 0.0
+    gemm_saved = 0.0
     attention = 0.0
 
     @classmethod
     def reset(cls, enabled=True):
-        cls.enabled, cls.gemm, cls.attention = enabled, 0.0, 0.0
+        cls.enabled, cls.gemm, cls.gemm_saved, cls.attention = enabled, 0.0, 0.0, 0.0
 
 
 _split_ws = {}      # (device, stream) -> grow-only fp32 scratch for split-K partial sums (stream-ordered reuse)
@@ -79,6 +82,8 @@ def gemm(desc, k_flop=None):
     if FlopCounter.enabled:
         cols = desc.N * (2 if desc.geglu else 1)
         FlopCounter.gemm += 2.0 * desc.M * cols * (desc.K if k_flop is None else k_flop) * desc.batch0 * desc.batch1
+        if k_flop is not None:
+            FlopCounter.gemm_saved += 2.0 * desc.M * cols * (desc.K - k_flop) * desc.batch0 * desc.batch1
     lib = _lib.load()
     need = lib.vsx_gemm_workspace(ctypes.byref(desc)) if (desc.M <= 20480 and desc.K >= 768) else 0
     stream = _stream()
