@@ -62,7 +62,10 @@ def test_shared_cfg_prefix_equals_the_duplicated_batch(setup):
     dup = one.expand(2, *one.shape[1:])
     cat = torch.cat([one, one])
     res = [r.half().to(DEV) for r in case['residuals']]
-    assert prod._shared_cfg_prefix(dup, txt) and not prod._shared_cfg_prefix(cat, txt)
+    one_row = torch.zeros(1, 8)          # stands for the [1, C] time-embedding row of a scalar timestep
+    assert prod._shared_cfg_prefix(dup, txt, one_row) and not prod._shared_cfg_prefix(cat, txt, one_row)
+    # two timestep values = two time-embedding rows: the stride-0 sample proves equal latents, not equal timesteps
+    assert not prod._shared_cfg_prefix(dup, txt, torch.zeros(2, 8))
     with torch.no_grad():
         a = prod(dup, 481, txt, down_block_additional_residuals=list(res)).sample.float().cpu()
         b = prod(cat, 481, txt, down_block_additional_residuals=list(res)).sample.float().cpu()
@@ -74,14 +77,61 @@ def test_shared_cfg_prefix_equals_the_duplicated_batch(setup):
     # processor) expects both halves: the sharing must step aside
     from videoswap_amd.attention import AttnProcessor, AttnProcessor2_0
     attn1 = prod.down_blocks[0].attentions[0].transformer_blocks[0].attn1
-    attn1.set_processor(type('Foreign', (AttnProcessor,), {'vsx_native': False})())
+    attn1.set_processor(type('Foreign', (AttnProcessor,), {'vsx_native': False, 'vsx_shareable': False})())
     try:
-        assert not prod._shared_cfg_prefix(dup, txt)
+        assert not prod._shared_cfg_prefix(dup, txt, one_row)
         with torch.no_grad():
             c = prod(dup, 481, txt, down_block_additional_residuals=list(res)).sample.float().cpu()
         assert rel_l2(c, b) < 5e-3         # (another arithmetic path: the LayerNorm in front of a foreign processor is not folded)
     finally:
         attn1.set_processor(AttnProcessor2_0())
+
+
+def test_shared_cfg_prefix_steps_aside_for_a_registered_controller_and_for_two_timesteps(setup):
+    """The Prompt-to-Prompt processors are `vsx_native` (they run on the kernels) but NOT shareable: below 32 x 32 latents the
+    controller is called on the first self-attention and splits its argument into the two CFG halves (attention_util.py:
+    `attn.shape[0] // 2`).  With a REAL `register_attention_control` at a 16 x 24 latent the stride-0 batch must give exactly
+    what the materialised batch gives (same kernels, same shapes), the store must have seen 2 F images on down-block 0, and
+    a [2] timestep tensor with two different values must not take item 0's embedding for both."""
+    from videoswap_amd import control
+    from videoswap_amd.attention import AttnProcessor2_0
+    blob, ora, prod = setup
+    case = blob['cases']['cfg_adapter_T3_16x24']
+    x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
+    one = x[:1].contiguous()
+    dup, cat = one.expand(2, *one.shape[1:]), torch.cat([one, one])
+    frames = x.shape[2]
+    pipe = type('P', (), {'unet': prod})()
+    seen = []
+
+    class Probe(control.AttentionStore):
+        def __call__(self, attn, is_cross, place_in_unet):
+            seen.append((place_in_unet, is_cross, attn.shape[0]))
+            return super().__call__(attn, is_cross, place_in_unet)
+    try:
+        with torch.no_grad():
+            control.register_attention_control(pipe, Probe())
+            assert not prod._shared_cfg_prefix(dup, txt, torch.zeros(1, 8))
+            a = prod(dup, 481, txt).sample
+            heads = prod.down_blocks[0].attentions[0].transformer_blocks[0].attn1.heads
+            first = seen[0]
+            assert first[0] == 'down' and first[1] is False
+            assert first[2] in (2 * frames, 2 * frames * heads), f'the controller must see both CFG halves, got {first}'
+            control.register_attention_control(pipe, Probe())
+            b = prod(cat, 481, txt).sample
+            assert torch.equal(a, b)
+    finally:
+        for name, m in prod.named_modules():
+            if m.__class__.__name__ == 'Attention' and ('attn1' in name or 'attn2' in name):
+                m.set_processor(AttnProcessor2_0())
+    # two different timesteps on a stride-0 sample: every batch item gets its own embedding row
+    with torch.no_grad():
+        t2 = torch.tensor([481, 21])
+        both = prod(dup, t2, txt).sample
+        item1 = prod(cat, torch.tensor([21, 21]), txt).sample
+        item0 = prod(cat, torch.tensor([481, 481]), txt).sample
+    assert rel_l2(both[1].float(), item1[1].float()) < 2e-3 and rel_l2(both[0].float(), item0[0].float()) < 2e-3
+    assert rel_l2(both[1].float(), item0[1].float()) > 1e-2, 'item 1 must not run with item 0\'s timestep'
 
 
 def test_unet_output_object_and_determinism(setup):

@@ -132,6 +132,7 @@ class _FusedProcessor:
     """Fused flash attention (never materialises the probabilities)."""
     vsx_native = True
     vsx_graph_safe = True       # launches only: may run inside a HIP-graph capture
+    vsx_shareable = True        # stateless: identical batch items may share one call (unet._shared_cfg_prefix)
 
     def __init__(self, cross_attention_idx=None):
         self.cross_attention_idx = cross_attention_idx

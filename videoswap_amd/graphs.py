@@ -16,7 +16,7 @@ from . import ops
 
 
 class _Entry:
-    __slots__ = ('graph', 'sample', 'semb', 'text', 'residuals', 'out', 'flop_gemm', 'flop_attention', 'keep')
+    __slots__ = ('graph', 'sample', 'semb', 'text', 'residuals', 'out', 'flop_gemm', 'flop_attention', 'flop_gemm_saved', 'keep')
 
 
 class GraphCache:
@@ -66,6 +66,7 @@ class GraphCache:
         if ops.FlopCounter.enabled:      # the replayed launches do not pass through the Python wrappers
             ops.FlopCounter.gemm += e.flop_gemm
             ops.FlopCounter.attention += e.flop_attention
+            ops.FlopCounter.gemm_saved += e.flop_gemm_saved
         return e.out.clone()
 
     def _capture(self, unet, sample, silu_emb, text, residuals):
@@ -92,8 +93,8 @@ class GraphCache:
         torch.cuda.synchronize()
         ops.prof_pause(True)          # hipEvent pairs cannot be recorded inside a capture
         fc = ops.FlopCounter
-        saved = (fc.enabled, fc.gemm, fc.attention)
-        fc.enabled, fc.gemm, fc.attention = True, 0.0, 0.0
+        saved = (fc.enabled, fc.gemm, fc.attention, fc.gemm_saved)
+        fc.enabled, fc.gemm, fc.attention, fc.gemm_saved = True, 0.0, 0.0, 0.0
         try:
             e.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(e.graph):
@@ -102,8 +103,8 @@ class GraphCache:
             e.keep = ops.fold_cache_tensors()
         finally:
             StepInvariantCache.bypass = False
-            e.flop_gemm, e.flop_attention = fc.gemm, fc.attention
-            fc.enabled, fc.gemm, fc.attention = saved
+            e.flop_gemm, e.flop_attention, e.flop_gemm_saved = fc.gemm, fc.attention, fc.gemm_saved
+            fc.enabled, fc.gemm, fc.attention, fc.gemm_saved = saved
             ops.prof_pause(False)
         self.captures += 1
         return e

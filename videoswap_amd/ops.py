@@ -107,6 +107,7 @@ LN_FUSE = os.environ.get('VSX_LN_FUSE', '1') != '0'     # 0: every LayerNorm run
 
 # VSX_ROW_STATS_PRODUCER=0: LayerNorm row statistics always by the standalone pass (A/B runs)
 ROW_STATS_FROM_PRODUCER = os.environ.get('VSX_ROW_STATS_PRODUCER', '1') != '0'
+ROW_STATS_MAX_PARTS = 64           # vsx_row_stats_combine's limit (norm.hip): N <= 3200 on the persistent kernel's 6 parts per 320 columns
 
 
 class DeferredLN:
@@ -289,7 +290,7 @@ def linear(x, weight, bias=None, residual=None, geglu=False, out=None, row_stats
     parts = None
     if row_stats and ln is None and not geglu and ROW_STATS_FROM_PRODUCER:
         nparts = int(_lib.load().vsx_gemm_rowstats_parts(ctypes.byref(d)))
-        if nparts > 0:
+        if 0 < nparts <= ROW_STATS_MAX_PARTS:      # (a hint, never an obligation: wider outputs take the stand-alone statistics pass)
             parts = torch.empty(M, nparts, 2, dtype=torch.float32, device=x.device)
             d.rowstats, d.rowstats_parts = parts.data_ptr(), nparts
     gemm(d)
@@ -384,8 +385,8 @@ def _subpixel_eligible(nimg, Hs, Ws, C1, Cout, ks, stride, x2, rowvec, residual,
     if not CONV_SUBPIXEL or ks != 3 or stride != 1 or x2 is not None or rowvec is not None or residual is not None \
             or padding is not None or C1 % 64 or Cout % 320:
         return False
-    if _options.get('gemm_pp', 1) not in (1, 2) or (_options.get('tile_tune', 0) & 15):
-        return False                    # the persistent kernel is switched off / a tile is forced (A/B runs, tests)
+    if _options.get('gemm_pp', 1) not in (1, 2) or _options.get('tile_tune', 0) != 0:
+        return False                    # the persistent kernel is switched off / a tile or a K split is forced (A/B runs, tests)
     mc = nimg * Hs * Ws
     return mc % 256 == 0 and (4 * mc // 256) * (Cout // 320) >= 192
 

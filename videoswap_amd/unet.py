@@ -41,6 +41,12 @@ def _native(attn):
     return getattr(attn.processor, 'vsx_native', False)
 
 
+def _shareable(attn):
+    """May this attention run once for two identical batch items?  Only the plain fused processors: they look at nothing but
+    their arguments (the controller processors are `vsx_native` as well, but hand per-batch-half probabilities to host state)."""
+    return getattr(attn.processor, 'vsx_shareable', False)
+
+
 # ------------------------------------------------------------------------------------------------
 # resnet.py
 # ------------------------------------------------------------------------------------------------
@@ -657,7 +663,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         # stride-0 batch view (`latents.expand(2, ...)`: VideoSwapPipeline does), conv_in, the first resnet and the first
         # self-attention (N = H*W keys: the largest attention launch of the model) run once for both halves.
         shared_geo = None
-        if self._shared_cfg_prefix(sample, encoder_hidden_states):
+        if self._shared_cfg_prefix(sample, encoder_hidden_states, silu_emb):
             shared_geo = Geometry(1, F)
             x = ops.pack_latents(sample[:1].contiguous(), 8)
         else:
@@ -725,12 +731,16 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         self._weights_epoch = getattr(self, '_weights_epoch', 0) + 1
         return super()._apply(fn, *args, **kwargs)
 
-    def _shared_cfg_prefix(self, sample, text):
+    def _shared_cfg_prefix(self, sample, text, silu_emb):
         """Can the two batch items share everything in front of the first cross-attention?  Only when the caller PROVES
-        that they are identical (a stride-0 batch dimension), the first block is a cross-attention block whose first
-        self-attention runs on this package's fused processor (a controller hooked there expects both halves), and the
-        clip is not frame-sharded."""
+        that they are identical (a stride-0 batch dimension) AND share the timestep (one time-embedding row: a [2] timestep
+        tensor gives two rows, and the shared prefix would hand item 0's row to both), the first block is a cross-attention
+        block whose first self- and cross-attention run on this package's plain fused processors (a Prompt-to-Prompt
+        controller hooked there is `vsx_native` too, but it expects both halves of the batch: below 32 x 32 latents it is
+        called on that very layer), and the clip is not frame-sharded."""
         if sample.shape[0] != 2 or sample.stride(0) != 0 or self._frame_shard is not None:
+            return False
+        if silu_emb.shape[0] != 1:
             return False
         if text is None or text.shape[0] != 2 or os.environ.get('VSX_CFG_SHARED_PREFIX', '1') == '0':
             return False
@@ -738,7 +748,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         if not getattr(blk, 'has_cross_attention', False) or len(blk.attentions) == 0:
             return False
         tb = blk.attentions[0].transformer_blocks[0]
-        return _native(tb.attn1) and _native(tb.attn2)
+        return _shareable(tb.attn1) and _shareable(tb.attn2)
 
     def _graphable(self, sample, silu_emb, text):
         if self._frame_shard is not None or not sample.is_cuda or silu_emb.shape[0] != 1:
