@@ -326,6 +326,43 @@ int main(int argc, char** argv) {
         printf("%-58s %s\n", "  ... bit-identical (default K order)", same ? "ok" : "FAIL");
         n_bad += same ? 0 : 1;
     }
+    if (only < 0 || only == nplain + 8) {
+        // XCD BLOCK GRID of the tile kernels (gemm.hip): forced tiles / K slices so that problems this small have enough work
+        // items; every case under the linear walk (xcd_walk 0) and under the block grid must agree bit for bit (the walk only
+        // decides WHICH workgroup computes a tile), the block grid must actually have been chosen, and both match the
+        // double-precision result (run_plain / run_conv report that)
+        struct G { const char* name; long M, N, K; long tune; bool splitk; int want_gm; };
+        const G cases[] = {{"XCD grid 4x2: 128x160 tiles, 8 x 4 tiles (1024x640x128)", 1024, 640, 128, 2, false, 4},
+                           {"XCD grid 2x4: 128x320 tiles x 2 K slices (512x640x256)", 512, 640, 256, (2 << 8), true, 2},
+                           {"XCD grid 1x8: 128x320 tiles x 4 K slices (256x640x512)", 256, 640, 512, (4 << 8), true, 1},
+                           {"XCD grid 1x8: 128x320 tile x 8 K slices (128x640x1024)", 128, 640, 1024, (8 << 8), true, 1}};
+        for (const G& g : cases) {
+            Plain c = {g.name, g.M, g.N, g.K, true, false, false, false, false, 0, 0, 0, g.splitk};
+            vsx_set_option("tile_tune", g.tune);
+            vsx_set_option("xcd_walk", 0);
+            rng_state = 1234u;
+            const auto a = run_plain(c, false);
+            const int gm0 = g_last_xcd_gm;
+            vsx_set_option("xcd_walk", 1);
+            rng_state = 1234u;
+            const auto b = run_plain(c, true);
+            const int gm1 = g_last_xcd_gm;
+            const bool same = memcmp(a.data(), b.data(), a.size() * sizeof(half_t)) == 0;
+            printf("%-58s %s (gm %d -> %d)\n", "  ... bit-identical to the linear walk, grid chosen", same && gm0 == 0 && gm1 == g.want_gm ? "ok" : "FAIL", gm0, gm1);
+            n_bad += same && gm0 == 0 && gm1 == g.want_gm ? 0 : 1;
+        }
+        vsx_set_option("tile_tune", (2 << 8));
+        vsx_set_option("xcd_walk", 0);
+        rng_state = 77u;
+        const auto a = run_conv("conv3x3 8x8x8 192->640, 128x320 tiles x 2 K slices, linear walk", 8, 8, 8, 192, 0, 640, 3, 1, 0, true, 0, true);
+        vsx_set_option("xcd_walk", 1);
+        rng_state = 77u;
+        const auto b = run_conv("conv3x3 8x8x8 192->640, 128x320 tiles x 2 K slices, XCD block grid", 8, 8, 8, 192, 0, 640, 3, 1, 0, true, 0, true);
+        const bool same = memcmp(a.data(), b.data(), a.size() * sizeof(half_t)) == 0;
+        printf("%-58s %s (gm %d)\n", "  ... bit-identical, grid chosen", same && g_last_xcd_gm > 0 ? "ok" : "FAIL", g_last_xcd_gm);
+        n_bad += same && g_last_xcd_gm > 0 ? 0 : 1;
+        vsx_set_option("tile_tune", 0);
+    }
     printf(n_bad ? "%d check(s) FAILED\n" : "all checks passed\n", n_bad);
     return n_bad ? 1 : 0;
 }

@@ -94,13 +94,23 @@ def time_once(fn, reps):
     return a.elapsed_time(b) / reps
 
 
+def apply(v):
+    """variant = (name, gemm_pp[, pp_sched[, tile_tune[, xcd_walk]]])"""
+    ops.set_option('gemm_pp', v[1])
+    ops.set_option('pp_sched', v[2] if len(v) > 2 else 0)
+    ops.set_option('tile_tune', v[3] if len(v) > 3 else 0)
+    ops.set_option('xcd_walk', v[4] if len(v) > 4 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=2)
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--reps', type=int, default=4)
     ap.add_argument('--scheds', default='', help='comma-separated pp_sched values: compare option bits instead of tile sizes')
-    ap.add_argument('--variants', default='', help='comma-separated name:gemm_pp:pp_sched:tile_tune')
+    ap.add_argument('--variants', default='', help='comma-separated name:gemm_pp:pp_sched:tile_tune[:xcd_walk]')
+    ap.add_argument('--base', default='', help='name:gemm_pp:pp_sched:tile_tune[:xcd_walk] of the baseline column (default tile:0:0:0)')
+    ap.add_argument('--levels', default='', help='comma-separated latent sides (64,32,16,8): only the shapes of these levels')
     ap.add_argument('--auto-scheds', default='', help='comma-separated pp_sched values under the automatic dispatch (gemm_pp = 1)')
     ap.add_argument('--bm', type=int, default=256, choices=(128, 256), help='row tile of the --scheds comparison')
     ap.add_argument('--kinds', default='', help="comma-separated subset of plain,geglu,conv (default: all)")
@@ -113,6 +123,8 @@ def main():
         variants = [('tile', 0, 0)] + [(label(n), 2 if args.bm == 256 else 3, int(n)) for n in args.scheds.split(',')]
     if args.variants:           # free form: name:gemm_pp:pp_sched:tile_tune (option "tile_tune": gemm.hip)
         variants = [('tile', 0, 0)] + [(v.split(':')[0],) + tuple(int(x) for x in v.split(':')[1:]) for v in args.variants.split(',')]
+    if args.base:
+        variants[0] = ('tile',) + tuple(int(x) for x in args.base.split(':')[1:])
     if args.auto_scheds:        # the product's own dispatch (gemm_pp = 1) under different pp_sched bits; 'tile' stays the baseline column
         variants = [('tile', 0, 0)] + [(f'auto/s{int(n)}', 1, int(n)) for n in args.auto_scheds.split(',')]
     print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
@@ -121,13 +133,17 @@ def main():
     for kind, name, a, count in shapes(args.batch):
         if args.kinds and kind not in args.kinds.split(','):
             continue
+        if args.levels:
+            lvl = a['hw'] if kind == 'conv' else {131072: 64, 32768: 32, 8192: 16, 65536: 64, 16384: 32, 4096: 16}.get(a['M'], 0)
+            if str(lvl) not in args.levels.split(','):
+                continue
         torch.manual_seed(0)
         fn, flop = make(kind, a)
         fns = {v[0]: fn for v in variants}
         ts = {v[0]: [] for v in variants}
         outs = {}
         for v in variants:                      # warm every variant (first launch sets the LDS attribute)
-            ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2]); ops.set_option('tile_tune', v[3] if len(v) > 3 else 0)
+            apply(v)
             outs[v[0]] = fns[v[0]]()
         torch.cuda.synchronize()
         bad = [k for k, o in outs.items() if not torch.equal(o, outs['tile'])]
@@ -140,7 +156,7 @@ def main():
             # the order rotates round by round: a variant's time depends on what ran just before it (the later columns of a
             # fixed order came out 1 - 4 % faster on the long convolutions, profiles/r04_gemm_rotation_ab_b*.txt)
             for v in variants[rnd % len(variants):] + variants[:rnd % len(variants)]:
-                ops.set_option('gemm_pp', v[1]); ops.set_option('pp_sched', v[2]); ops.set_option('tile_tune', v[3] if len(v) > 3 else 0)
+                apply(v)
                 ts[v[0]].append(time_once(fns[v[0]], args.reps))
         med = {k: sorted(x)[len(x) // 2] * 1000.0 for k, x in ts.items()}
         best = min(med, key=med.get)
@@ -149,7 +165,7 @@ def main():
         print(f'{name:44s} {count:3d} ' + ' '.join(f'{med[v[0]]:9.1f}' for v in variants) +
               f'   {flop / med[best] / 1e6:7.1f}  {med["tile"] / med[best]:6.2f}x  {best:9s}'
               f' {med["tile"] * count / 1000:6.2f} -> {med[best] * count / 1000:6.2f}', flush=True)
-    ops.set_option('gemm_pp', 1); ops.set_option('pp_sched', 0); ops.set_option('tile_tune', 0)
+    apply(('auto', 1))
     print(f'# GEMM time per forward (listed shapes): tile kernels {tot_old:.2f} ms, best-of {tot_best:.2f} ms')
 
 

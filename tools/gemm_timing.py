@@ -32,12 +32,12 @@ def run(M, N, K, iters=5):
     _lib.LIB_PATH = LIB
     lib = _lib.load()
     tile = int(os.environ.get('VSX_TUNE_TILE', '1'))
-    BM, BN, NW = {1: (128, 320, 8), 2: (128, 160, 4), 3: (256, 320, 16)}[tile]
+    BM, BN, NW = {1: (128, 320, 8), 2: (128, 160, 4), 3: (256, 320, 16), 4: (128, 128, 4), 5: (64, 128, 4), 6: (64, 64, 4)}[tile & 15]
     x = torch.randn(M, K, device='cuda', dtype=torch.float16)
     w = torch.randn(N, K, device='cuda', dtype=torch.float16) * 0.02
     out = torch.empty(M, N, device='cuda', dtype=torch.float16)
     nblk = ((M + BM - 1) // BM) * ((N + BN - 1) // BN)
-    ws = torch.zeros(nblk * NW * 4, dtype=torch.int64, device='cuda')
+    ws = torch.zeros(nblk * NW * 8, dtype=torch.int64, device='cuda')
     d = _lib.GemmDesc()
     d.M, d.N, d.K = M, N, K
     d.batch0 = d.batch1 = 1
@@ -45,6 +45,11 @@ def run(M, N, K, iters=5):
     d.B = w.data_ptr(); d.ldb = K
     d.C = out.data_ptr(); d.ldc = N
     d.alpha = 1.0
+    if os.environ.get('VSX_TIMING_RES'):
+        res = torch.randn(M, N, device='cuda', dtype=torch.float16)
+        bias = torch.randn(N, device='cuda', dtype=torch.float16)
+        d.residual = res.data_ptr(); d.ldr = N
+        d.bias = bias.data_ptr()
     d.workspace = ws.data_ptr(); d.workspace_bytes = ws.numel() * 8
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(iters):
@@ -55,7 +60,8 @@ def run(M, N, K, iters=5):
     _lib.check(lib.vsx_gemm_f16(ctypes.byref(d), ctypes.c_void_p(s)), 'gemm')
     b.record(); b.synchronize()
     us = a.elapsed_time(b) * 1e3
-    t = ws.view(nblk, NW, 4).double()
+    full = ws.view(nblk, NW, 8)
+    t = full[:, :, :4].double()
     nslab = (K + 63) // 64
     per = t.mean(dim=(0, 1)) / max(nslab - 1, 1)
     tot = per.sum().item()
@@ -66,6 +72,23 @@ def run(M, N, K, iters=5):
         print(f'    {n:32s} {v:8.0f} cyc  {100 * v / tot:5.1f}%')
     wv = t.mean(dim=0) / max(nslab - 1, 1)
     print('    per-wave totals:', [f'{v:.0f}' for v in wv.sum(dim=1).tolist()])
+    phases(full, us)
+
+
+def phases(full, us):
+    """Absolute stamps (entries 4-7 of a wave's record: kernel entry, first slab multiplied, last slab multiplied, stores
+    acknowledged): where the launch's wall time goes besides the K loop."""
+    st = full[:, :, 4:8].double()
+    t0 = st[:, :, 0].min().item()
+    span = st[:, :, 3].max().item() - t0
+    rel = st - t0
+    b, l0, l1, e = (rel[:, :, i] for i in range(4))
+    print(f'    launch span {span:.0f} cycles = {us:.1f} us by the events -> ~{span / us / 1e3:.2f} GHz if the span were the whole launch')
+    print(f'    entry (first ... last wave)        {b.min().item():8.0f} ... {b.max().item():8.0f}')
+    print(f'    prologue: entry -> first slab     mean {(l0 - b).mean().item():8.0f}  max {(l0 - b).max().item():8.0f}')
+    print(f'    K loop                            mean {(l1 - l0).mean().item():8.0f}  max {(l1 - l0).max().item():8.0f}')
+    print(f'    epilogue (stores acknowledged)    mean {(e - l1).mean().item():8.0f}  max {(e - l1).max().item():8.0f}')
+    print(f'    exit (first ... last wave)         {e.min().item():8.0f} ... {e.max().item():8.0f}')
 
 
 if __name__ == '__main__':

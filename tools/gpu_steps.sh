@@ -1,0 +1,89 @@
+#!/bin/bash
+# One parameterised GPU call: `gpurun --timeout N -- 'bash tools/gpu_steps.sh TAG step [step ...]'`.  Every step writes
+# gpurun_out/TAG_<step>.txt (merged back by gpurun) and prints its tail; a failing step does not stop the following ones.
+# Steps (round 5 folded the one-off gpu_r4*.sh scripts into this file):
+#   lib            the library loads; prints its source digest
+#   square         tools/gemm_square.py        calibration of the persistent GEMM on square problems
+#   ksweep         tools/k_sweep.py            fixed cost against per-slab cost of the small-M GEMMs
+#   xcdab          tools/gemm_ab.py            XCD block grid of the tile kernels on / off, 16x16 and 8x8 levels, B = 1 and 2
+#   timing         tools/gemm_timing.py        phase stamps of the tile kernels on the small-M shapes (timing build)
+#   ab:<args>      tools/gemm_ab.py <args>     free-form A/B ("," for spaces)
+#   py:<args>      python <args>               any tool ("," for spaces)
+#   kernels        pytest tests/test_kernels_gpu.py
+#   pytest         the whole -m gpu suite
+#   bench          python bench.py             (default line, both baseline legs)
+#   benchq         python bench.py --no-cpu-baseline --steps 2 --warmup 1
+#   trace          rocprofv3 --kernel-trace --stats of a 10 + 10-step clip -> TAG_kernel_stats.txt
+#   pmcshape       tools/pmc_by_shape.sh       per-shape fabric traffic (also refreshes profiles/gemm_hbm_traffic.json)
+#   pmcsq          tools/pmc_sq.sh             SQ counters (MFMA busy, LDS conflicts)
+#   attn           tools/attn_ab.py
+#   train          tools/train_bench.py
+#   dist1          the distributed branches of bench.py on ONE rank (torchrun --nproc-per-node 1, VSX_FORCE_DISTRIBUTED=1)
+TAG=${1:-r05}
+shift
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+T0=$(date +%s)
+el() { echo "[t+$(( $(date +%s) - T0 )) s] $*"; }
+show() { tail -n ${2:-12} $O/${TAG}_$1.txt | cut -c1-${3:-260}; }
+for STEP in "$@"; do
+  case $STEP in
+    lib)
+      python -c "from videoswap_amd import _lib; l=_lib.load(); print('lib ok', l.vsx_source_digest().decode()[:12])" > $O/${TAG}_lib.txt 2>&1; show lib 3 ;;
+    square)
+      timeout 300 python tools/gemm_square.py > $O/${TAG}_square.txt 2>&1; show square 30 ;;
+    ksweep)
+      timeout 600 python tools/k_sweep.py > $O/${TAG}_ksweep.txt 2>&1; show ksweep 60 ;;
+    xcdab)
+      for B in 2 1; do
+        timeout 400 python tools/gemm_ab.py --batch $B --levels 16,8 --rounds 7 --base auto:1:0:0:0 --variants grid:1:0:0:1 > $O/${TAG}_xcdab_b$B.txt 2>&1
+        tail -n 40 $O/${TAG}_xcdab_b$B.txt | cut -c1-200
+      done ;;
+    timing)
+      {
+        for spec in "2 4096 1280 1280" "18 4096 1280 1280" "2 4096 1280 320" "18 4096 1280 5120" "6 1024 1280 1280" "1 4096 1280 1280" "18 8192 1280 1280"; do
+          set -- $spec
+          VSX_TIMING_RES=1 VSX_TUNE_TILE=$1 timeout 120 python tools/gemm_timing.py run $2 $3 $4
+        done
+      } > $O/${TAG}_timing.txt 2>&1; show timing 120 ;;
+    ab:*)
+      A=${STEP#ab:}; N=$(echo "$A" | md5sum | cut -c1-6)
+      timeout 900 python tools/gemm_ab.py ${A//,/ } > $O/${TAG}_ab_$N.txt 2>&1; echo "# gemm_ab ${A//,/ }"; show ab_$N 70 ;;
+    py:*)
+      A=${STEP#py:}; N=$(echo "$A" | md5sum | cut -c1-6)
+      timeout 900 python ${A//,/ } > $O/${TAG}_py_$N.txt 2>&1; echo "# python ${A//,/ }"; show py_$N 70 ;;
+    kernels)
+      ( time timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -rf ) > $O/${TAG}_kernels.txt 2>&1; show kernels 15 ;;
+    pytest)
+      ( time timeout 1700 python -m pytest tests -m gpu -x -q --durations=12 -rf ) > $O/${TAG}_pytest.txt 2>&1; show pytest 24 ;;
+    bench)
+      timeout 500 python bench.py > $O/${TAG}_bench.txt 2>&1; show bench 1 3500 ;;
+    benchq)
+      timeout 400 python bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/${TAG}_benchq.txt 2>&1; show benchq 1 3500 ;;
+    trace)
+      ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -o r05 -- python $R/bench.py --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --prof-samples 0 > $O/${TAG}_prof.log 2>&1 )
+      DB=$(find $O/${TAG}_prof -name '*.db' | head -n 1)
+      [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $O/${TAG}_kernel_stats.txt 2>&1
+      find $O/${TAG}_prof -type f -size +4M -delete 2>/dev/null
+      head -n 24 $O/${TAG}_kernel_stats.txt | cut -c1-180; tail -n 3 $O/${TAG}_kernel_stats.txt | cut -c1-200 ;;
+    pmcshape)
+      bash tools/pmc_by_shape.sh ${TAG}_pmc_shape > $O/${TAG}_pmc_shape.txt 2>&1; show pmc_shape 2
+      cp $O/${TAG}_pmc_shape/gemm_hbm_traffic.json $R/profiles/gemm_hbm_traffic.json 2>/dev/null
+      cp $O/${TAG}_pmc_shape/gemm_hbm_traffic.json $O/${TAG}_gemm_hbm_traffic.json 2>/dev/null ;;
+    pmcsq)
+      bash tools/pmc_sq.sh ${TAG}_pmc_sq; cat $O/${TAG}_pmc_sq/passes.txt; head -n 24 $O/${TAG}_pmc_sq/summary.txt | cut -c1-200 ;;
+    attn)
+      timeout 300 python tools/attn_ab.py > $O/${TAG}_attn.txt 2>&1; show attn 30 ;;
+    train)
+      timeout 300 python tools/train_bench.py --steps 3 > $O/${TAG}_train.txt 2>&1; show train 4 ;;
+    dist1)
+      VSX_FORCE_DISTRIBUTED=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+        bench.py --gpus 1 --steps 1 --warmup 0 --ddim-steps 4 --no-cpu-baseline > $O/${TAG}_dist1_clip.txt 2>&1; show dist1_clip 2 3000
+      VSX_FORCE_DISTRIBUTED=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 \
+        bench.py --gpus 1 --config 4 --frames 32 --steps 1 --warmup 0 --ddim-steps 2 --no-cpu-baseline > $O/${TAG}_dist1_long.txt 2>&1; show dist1_long 2 3000 ;;
+    *) echo "unknown step $STEP" ;;
+  esac
+  el $STEP
+done

@@ -31,6 +31,7 @@
 // transposed store (V^T for the attention kernel).  Accumulators hold C^T (SWAP) so a lane owns one output row and 4
 // consecutive columns per register quad: 8-byte vector loads/stores in the epilogue.
 #include "gemm_common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 #include <stdlib.h>
@@ -84,24 +85,45 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
     const int l31 = lane & 31, hi = lane >> 5;
+#ifdef VSX_GEMM_TIMING
+    const long t_begin = (long)clock64();      // absolute stamps (long[block][wave][8], entries 4-7): entry, first / last slab, exit
+#endif
 
     // XCD-aware tile order: the dispatcher places workgroup b on XCD b % 8 (each XCD has its own 4 MiB L2), so give
     // every XCD a CONTIGUOUS range of the (tile_m, tile_n) space.  Bijective for any grid size; placement only affects
     // speed, never results.
-    int wg = blockIdx.x;
-    {
+    int tile_n, tile_m, split;
+    if (p.xcd_gm > 0) {
+        // XCD BLOCK GRID (unbatched launches whose work items number a multiple of 8; the host picks gm, launch()).  The work
+        // items are (tile_m, np) with np = K slice * tiles_n + tile_n, one operand panel each way: A rows tile_m (of the
+        // slice), weight rows np.  The eight XCDs form a gm x (8 / gm) grid over that space and an XCD's workgroups walk its
+        // block rows fastest, so that an XCD fetches tiles_m / gm activation panels and NP * gm / 8 weight panels through
+        // its L2 instead of (linear walk) tiles_m / 8 and ALL of the weights — which is what the small-M, long-K launches of
+        // the 16x16 / 8x8 levels move: every XCD streamed the whole weight matrix, 5 - 8 x the algorithmic bytes, and the
+        // 8x8 convolutions sat on the fabric's read rate (profiles/r04_gemm_traffic_by_shape_tap_inner.txt).
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int gm = p.xcd_gm;
+        const int RB = p.tiles_m / gm;
+        const int CB = (p.tiles_n * (p.splitk > 1 ? p.splitk : 1)) / (8 / gm);
+        const int lr = local % RB;
+        const int np = (xcd / gm) * CB + local / RB;
+        tile_m = (xcd % gm) * RB + lr;
+        tile_n = np % p.tiles_n;
+        split = np / p.tiles_n;
+    } else {
+        int wg = blockIdx.x;
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
         const int xcd = wg & 7, local = wg >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        tile_n = wg % p.tiles_n;
+        tile_m = wg / p.tiles_n;
+        split = p.splitk > 1 ? (int)blockIdx.z : 0;
     }
-    const int tile_n = wg % p.tiles_n;
-    const int tile_m = wg / p.tiles_n;
     const long m0 = (long)tile_m * BM;
     // geglu: a BN-row tile of B (h and g rows interleaved) produces BN/2 output columns
     const long n0 = p.geglu ? (long)tile_n * (BN / 2) : (long)tile_n * BN;
 
-    const int split = p.splitk > 1 ? (int)blockIdx.z : 0;
-    const int z = p.splitk > 1 ? 0 : (int)blockIdx.z;
+    const int z = (p.splitk > 1 || p.xcd_gm > 0) ? 0 : (int)blockIdx.z;
     const int z0 = z / p.batch1, z1 = z - z0 * p.batch1;
     const half_t* Ab = p.A + z0 * p.a_bs0 + z1 * p.a_bs1;
     const half_t* Bb = p.B + z0 * p.b_bs0 + z1 * p.b_bs1;
@@ -399,7 +421,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     // fragment immediately before the MFMA that consumed it (s_waitcnt lgkmcnt(0) in front of every MFMA) and a lone
     // workgroup ran at 38 % of the MFMA rate (tools/tile_probe.py).
 #ifdef VSX_GEMM_TIMING
-    long t_seg[4] = {0, 0, 0, 0}, t_last = 0;
+    long t_seg[4] = {0, 0, 0, 0}, t_last = 0, t_loop0 = 0;
 #endif
     constexpr bool PIPE = (NW <= 8) && (TM * TN < 10);
     if constexpr (PIPE) {
@@ -411,7 +433,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         const bool late = NW >= 8 && wave >= NW / 2;      // second wave of each SIMD: stages one k-step later
         i_on = false;
 #ifdef VSX_GEMM_TIMING
-        t_last = (long)clock64();
+        t_last = t_loop0 = (long)clock64();
 #endif
         for (int kt = 0; kt + 1 < nloc; ++kt) {
             const unsigned char* sb = smem + (kt & (NSTAGE - 1)) * STAGE;
@@ -455,7 +477,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     } else {
         const bool late16 = NW >= 16 && ((wave >> 2) & 1);
 #ifdef VSX_GEMM_TIMING
-        t_last = (long)clock64();
+        t_last = t_loop0 = (long)clock64();
 #endif
         for (int kt = 0; kt < nloc; ++kt) {
             wait_slab(kt);
@@ -488,10 +510,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     }
 
 #ifdef VSX_GEMM_TIMING
-    if (lane == 0 && p.ws) {
-        long* o = reinterpret_cast<long*>(p.ws) + ((long)blockIdx.x * NW + wave) * 4;
-        for (int k = 0; k < 4; ++k) o[k] = t_seg[k];
+    long* const t_out = p.ws && p.splitk <= 1 ? reinterpret_cast<long*>(p.ws) + ((long)blockIdx.x * NW + wave) * 8 : nullptr;
+    if (lane == 0 && t_out) {
+        for (int k = 0; k < 4; ++k) t_out[k] = t_seg[k];
+        t_out[4] = t_begin; t_out[5] = t_loop0; t_out[6] = (long)clock64();
     }
+#define TSTAMP_END() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (lane == 0 && t_out) t_out[7] = (long)clock64(); } while (0)
+#else
+#define TSTAMP_END() do { } while (0)
 #endif
     // ---------------- epilogue (32-bit element offsets: the host guarantees M*ldc, M*ldr < 2^31) ----------------
     half_t* Cb = p.C + z0 * p.c_bs0 + z1 * p.c_bs1;
@@ -787,6 +813,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             }
         }
     }
+    TSTAMP_END();
 }
 
 // split-K combine: out[m, n] = sum_z ws[z][m][n] + bias + rowvec + residual (fixed summation order: deterministic)
@@ -842,8 +869,46 @@ inline int plan_splitk(const vsx_gemm_desc* d, long tiles, bool eligible) {
     return s;
 }
 
+int g_last_xcd_gm = 0;       // diagnostics (tools/cpu_check/check_gemm_api.cpp reads it): the arrangement of the last tile-kernel launch
+
+// XCD BLOCK GRID (gemm_kernel): which gm x (8 / gm) arrangement of the XCDs over (tile_m, np) moves the fewest operand bytes
+// through the L2s.  Per XCD: (tiles_m / gm) x (K slices its column block meets) activation panels + NP * gm / 8 weight
+// panels.  Returns 0 (the linear walk: the same blocks as gm = 8 whenever tiles_m is a multiple of 8) unless another
+// arrangement is valid and cheaper.  Option "xcd_walk" (VSX_XCD_WALK) = 0 keeps the linear walk (A/B runs).
+int plan_xcd_grid(const GemmParams& p, const long tiles_m, const int bm, const int bn, const long nbatch) {
+    if (nbatch != 1 || gemm_option("xcd_walk") == 0) return 0;
+    const int splits = p.splitk > 1 ? p.splitk : 1;
+    const long np_total = (long)p.tiles_n * splits;
+    if ((tiles_m * np_total) % 8 != 0 || tiles_m * np_total < 16) return 0;
+    const long nk = (p.K + BK - 1) / BK;
+    const double kslice = (double)(splits > 1 ? (long)p.nk_per * BK : nk * BK);
+    const double taps = p.a_mode == 1 ? (double)(p.ks * p.ks) / (double)(p.stride * p.stride) : 1.0;    // windows of neighbouring pixels overlap
+    const double a_panel = (double)bm * kslice * 2.0 / (taps < 1.0 ? 1.0 : taps);
+    const double b_panel = (double)bn * kslice * 2.0;
+    auto cost = [&](const int gm) -> double {
+        const int gn = 8 / gm;
+        if (tiles_m % gm != 0 || np_total % gn != 0) return -1.0;
+        const long RB = tiles_m / gm, CB = np_total / gn;
+        long nsp = 1;                                   // K slices the widest-spanning column block meets
+        for (int b = 0; b < gn; ++b) {
+            const long lo = b * CB, hi = lo + CB - 1;
+            nsp = std::max(nsp, hi / p.tiles_n - lo / p.tiles_n + 1);
+        }
+        return (double)(RB * nsp) * a_panel + (double)CB * b_panel;
+    };
+    const double legacy = (tiles_m % 8 == 0) ? cost(8)
+                                             : (double)((tiles_m + 7) / 8 + 1) * splits * a_panel + (double)np_total * b_panel;
+    int best = 0;
+    double best_cost = legacy;
+    for (int gm = 4; gm >= 1; gm >>= 1) {
+        const double c = cost(gm);
+        if (c >= 0.0 && c < 0.95 * best_cost) { best = gm; best_cost = c; }
+    }
+    return best;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SWAP, int NSTAGE>
-int launch(const GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
+int launch(GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
     constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS ring exceeds 160 KiB");
     static bool attr_set = false;
@@ -853,7 +918,10 @@ int launch(const GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
+    p.tiles_m = (int)tiles_m;
+    p.xcd_gm = g_last_xcd_gm = plan_xcd_grid(p, tiles_m, BM, BN, nbatch);
     dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)(p.splitk > 1 ? p.splitk : nbatch));
+    if (p.xcd_gm > 0) grid = dim3((unsigned)(tiles_m * p.tiles_n * (p.splitk > 1 ? p.splitk : 1)), 1, 1);
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WAVES_M, WAVES_N, SWAP, NSTAGE>), grid, dim3(WAVES_M * WAVES_N * 64), smem,
                        stream, p);
     return vsx_check_launch("vsx_gemm_f16");
@@ -929,7 +997,7 @@ namespace vsxg {
 namespace {
 struct Option { const char* name; const char* env; long value; bool init; };
 Option g_options[] = {{"gemm_pp", "VSX_GEMM_PP", 1, false}, {"pp_sched", "VSX_PP_SCHED", 0, false},
-                      {"tile_tune", "VSX_TUNE_TILE", 0, false},
+                      {"tile_tune", "VSX_TUNE_TILE", 0, false}, {"xcd_walk", "VSX_XCD_WALK", 1, false},
                       {"attn_qb", "VSX_ATTN_QB", 0, false}};
 Option* find_option(const char* name) {
     for (auto& o : g_options)

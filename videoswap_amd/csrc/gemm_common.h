@@ -35,6 +35,8 @@ struct GemmParams {
     int tiles_total;                       // persistent kernel: number of output tiles
     int pp_flags;                          // persistent kernel: PP_* option bits (tile walk)
     int sp_Mc;                             // sub-pixel form of the nearest-2x convolution (upsample = 2): GEMM rows per (ph, pw) class, else 0
+    // workgroup-per-tile kernels: XCD block grid (gemm.hip, "XCD BLOCK GRID").  xcd_gm = 0: the linear walk (grid.z = K slices)
+    int xcd_gm, tiles_m;
 };
 
 // pp_flags: option bits of "pp_sched" / VSX_PP_SCHED.  Round 3 measured five candidates on the GPU
