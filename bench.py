@@ -32,6 +32,7 @@ MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak, /opt/skills/guides/MI355X_
 # reported beside the nominal peak, never instead of it
 MFMA_SUSTAINED_TFLOPS = 1820.0
 FRAME_EVAL_TFLOP = 1.1046     # algorithmic TFLOP of one frame-evaluation at T=16, 64x64
+HBM_COPY_TBPS = 6.29          # measured float4-copy rate, /opt/skills/guides/MI355X_MICROARCH.md (8.0 TB/s spec): the byte roofline
 
 
 def parse():
@@ -63,11 +64,11 @@ def parse():
     # hipEvent pairs around every 7th vsx_gemm_f16 launch (7 is coprime with the ~470 GEMM launches of a UNet call, so
     # every shape is sampled over the 100 calls of a clip); bracketing EVERY launch costs 5 % of the loop
     ap.add_argument('--prof-stride', type=int, default=7)
-    ap.add_argument('--graphs', action='store_true',
-                    help='HIP-graph replay of the UNet forward (every --prof-stride-th UNet call stays eager and '
-                         'carries the hipEvent brackets).  Off by default: the replay path has not been timed on '
-                         'hardware yet (round 2 ran out of GPU minutes), so the headline number is the eager one')
-    ap.add_argument('--no-graphs', action='store_true', help='(default) launch every kernel eagerly')
+    ap.add_argument('--clips-per-step', type=int, default=1,
+                    help='clips denoised TOGETHER in one step (latents [B,4,T,h,w]: UNet batch B in the inversion, 2B under CFG). '
+                         '1 = the headline workload; 2 = the throughput mode the default run also reports as a reading')
+    ap.add_argument('--no-batched-reading', action='store_true',
+                    help='skip the extra reading "R1e_two_clips_per_step" (one warm-up pair + one timed pair of clips, B = 2 / 4)')
     args = ap.parse_args()
     if args.frames == 0:
         args.frames = 64 if args.config == 4 else 16
@@ -144,7 +145,18 @@ def swap_clip(pipe, data, ddim_steps, lora, marks=None):
             pipe.invert = invert
 
 
+class _HostMark:
+    """stand-in for a device event where there is no device (the gloo plumbing test)"""
+    def __init__(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
 def _event():
+    if not torch.cuda.is_available():
+        return _HostMark()
     e = torch.cuda.Event(enable_timing=True)
     e.record()
     return e
@@ -158,8 +170,7 @@ def one_clip(pipe, data, ddim_steps, marks=None):
     inv = pipe.invert(latents=data['latents'], prompt_embeds=data['text'], num_inference_steps=ddim_steps).latents
     if marks is not None:
         marks.append(_event())
-    embeds = torch.cat([data['negative'], data['text']])
-    out = pipe(prompt=None, conditions=None, prompt_embeds=embeds[1:], negative_prompt_embeds=embeds[:1],
+    out = pipe(prompt=None, conditions=None, prompt_embeds=data['text'], negative_prompt_embeds=data['negative'],
                latents=inv, num_inference_steps=ddim_steps, guidance_scale=7.5, output_type='latent').videos
     return out
 
@@ -272,6 +283,29 @@ def gemm_traffic(frames, latent):
             f'{t["launches"]} launches of one inversion + one CFG step')
 
 
+def stack_clips(group):
+    """B clips denoised together: latents [B,4,T,h,w], text / negative [B,77,768] (the reference's batch axis, pipeline_videoswap.py:
+    478-550: `batch_size = len(prompt)`).  configs[2]'s conditions stay per clip and are only used with one clip per step."""
+    if len(group) == 1:
+        return group[0]
+    return dict(latents=torch.cat([c['latents'] for c in group]), text=torch.cat([c['text'] for c in group]),
+                negative=torch.cat([c['negative'] for c in group]), conditions=group[0]['conditions'])
+
+
+def timed_clips(run_clip, batches, ddim_steps, n_steps, barrier, marks=None):
+    """EXACTLY n_steps steps (one step = one batch of clips through inversion + sampling) between two barriers."""
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        if marks is not None:
+            marks.append(_event())                   # clip start | (inside the clip) end of the inversion | clip end
+        run_clip(batches[i % len(batches)], ddim_steps, marks)
+        if marks is not None:
+            marks.append(_event())
+    barrier()
+    return time.perf_counter() - t0
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -280,26 +314,40 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch multi-GPU runs with torch.distributed.run (one process per GPU)')
-    distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # VSX_FORCE_DISTRIBUTED=1 (tools/gpu_steps.sh dist1, under torchrun --nproc-per-node 1): take every multi-rank branch — the
+    # nccl process group, dist.barrier, max-over-ranks, FrameShard on the RCCL communicator with its side-stream event ordering —
+    # on ONE rank, so that the driver's first multi-GPU run is not the first execution of those lines
+    distributed = world > 1 or os.environ.get('VSX_FORCE_DISTRIBUTED') == '1'
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+    else:       # only the gloo plumbing test (tests/test_distributed.py) gets here, with the clip loop stubbed
+        device = torch.device('cpu')
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if device.type == 'cuda':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group('gloo')
 
     from videoswap_amd import ops
     from videoswap_amd.distributed import max_over_ranks as max_over
     from videoswap_amd.synthetic import synthetic_clip
     swap = args.config == 3
     longclip = args.config == 4
+    cps = max(args.clips_per_step, 1)
+    if cps > 1 and (swap or longclip):
+        raise SystemExit('--clips-per-step > 1 is the plain configs[1] workload only')
     lh, lw = args.latent_h or args.latent, args.latent_w or args.latent
-    pipe = build_pipeline(device, args.frames, swap=swap)
+    stub = os.environ.get('VSX_BENCH_STUB_CLIP') == '1'      # CPU plumbing test (tests/test_distributed.py): no model, no kernels
+    pipe = None if stub else build_pipeline(device, args.frames, swap=swap)
     shard = None
+    n_batches = max(args.steps, 1)
     if longclip:
         # configs[3]: ONE clip for the whole job (same seed on every rank), rank r denoises frames [r*T/N, (r+1)*T/N)
         clips = [synthetic_clip(seed=7000 + i, frames=args.frames, height=lh, width=lw, device=device)
-                 for i in range(max(args.steps, 1))]
-        if distributed:
+                 for i in range(n_batches)]
+        if distributed and not stub:
             from videoswap_amd.distributed import FrameShard
             shard = FrameShard(args.frames, exchange=args.exchange)          # nccl process group -> the C-ABI collectives
             shard.install(pipe.unet)
@@ -308,45 +356,37 @@ def main():
     else:
         # every rank owns different clips (seeded by rank); inputs resident in HBM before the timed region
         clips = [synthetic_clip(seed=1000 * rank + i, frames=args.frames, height=lh, width=lw,
-                                device=device) for i in range(max(args.steps, 1))]
+                                device=device) for i in range(n_batches * cps)]
+    batches = [stack_clips(clips[i * cps:(i + 1) * cps]) for i in range(n_batches)] if not longclip else clips
     marks = []
     if swap:
         lora = synthetic_edlora(pipe.unet.state_dict())
         run_clip = lambda data, steps, m=None: swap_clip(pipe, data, steps, lora, m)      # noqa: E731
     else:
         run_clip = lambda data, steps, m=None: one_clip(pipe, data, steps, m)             # noqa: E731
+    if stub:                                              # the metric / timing / collective code only
+        def run_clip(data, steps, m=None):                # noqa: F811
+            if m is not None:
+                m.append(_event())
+            time.sleep(0.01)
 
     def barrier():
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize()
+        if device.type == 'cuda':
+            torch.cuda.synchronize()
 
-    graphs = args.graphs and not args.no_graphs
-    if graphs:
-        # graph replay for the UNet forward; every prof_stride-th call runs eagerly and is the one whose GEMM launches
-        # are bracketed by hipEvents (ALL of them: same 1/stride sampling fraction as the eager mode's every-7th-launch)
-        pipe.unet.enable_hip_graphs(True, eager_every=args.prof_stride if args.prof_samples > 0 else 0)
-        if args.warmup == 0:
-            run_clip(clips[0], 1)                    # capture the two graphs (B=1, B=2) outside the timed region
     for i in range(args.warmup):
-        run_clip(clips[i % len(clips)], args.ddim_steps)
+        run_clip(batches[i % len(batches)], args.ddim_steps)
     barrier()
-    if graphs:
-        pipe.unet._graphs.on_eager = (lambda on: ops.prof_pause(not on))
 
     if shard is not None:
         shard.bytes_gathered = 0
     ops.FlopCounter.reset(True)
-    ops.prof_enable(args.prof_samples > 0, args.prof_samples, stride=1 if graphs else args.prof_stride)
-    if graphs:
-        ops.prof_pause(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        marks.append(_event())                       # clip start | (inside the clip) end of the inversion | clip end
-        run_clip(clips[i % len(clips)], args.ddim_steps, marks)
-        marks.append(_event())
-    barrier()
-    elapsed = time.perf_counter() - t0
+    prof = args.prof_samples > 0 and device.type == 'cuda'
+    if prof:
+        ops.prof_enable(True, args.prof_samples, stride=args.prof_stride)
+    elapsed = timed_clips(run_clip, batches, args.ddim_steps, args.steps, barrier, marks)
     # device time of the two halves of every clip (events on the launch stream; nothing was synchronised in between)
     inv_s = sum(marks[3 * i].elapsed_time(marks[3 * i + 1]) for i in range(args.steps)) * 1e-3
     smp_s = sum(marks[3 * i + 1].elapsed_time(marks[3 * i + 2]) for i in range(args.steps)) * 1e-3
@@ -354,18 +394,19 @@ def main():
         smp_s = max_over(smp_s, device)
         inv_s = max_over(inv_s, device)
     ops.FlopCounter.enabled = False
-    ops.prof_pause(False)
-    n_launch, gemm_ms, gemm_flop = ops.prof_collect()
-    ops.prof_enable(False, 0)
+    roof = ops.prof_collect_roofline(MFMA_PEAK_TFLOPS * 1e12, HBM_COPY_TBPS * 1e12) if prof else dict(n=0, ms=0.0)
+    if prof:
+        ops.prof_enable(False, 0)
 
     elapsed = max_over(elapsed, device)              # whole-job time = slowest rank
 
     # clip-parallel: every rank its own clips (weak scaling); long clip: the ranks share ONE clip per step (strong scaling)
-    clips_job = args.steps if longclip else world * args.steps
+    clips_job = args.steps if longclip else world * args.steps * cps
     frames_total = clips_job * args.frames
     value = frames_total / elapsed
     total_flop = (ops.FlopCounter.gemm + ops.FlopCounter.attention) * world
     evals = clips_job * args.frames * 3 * args.ddim_steps                   # (1 + 2) UNet frame-evals per DDIM step
+    per_clip = max(args.steps * cps, 1)
     out = {
         'metric': (f'denoised frames/sec, {args.frames}-frame 512^2 long clip @ 50 DDIM steps, frame axis sharded over the GPUs '
                    '(end to end: inversion + CFG sampling)' if longclip else
@@ -374,22 +415,24 @@ def main():
         'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 2), 'higher_is_better': True,
         'scaling': 'strong' if longclip else 'weak',
         'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-        'config': {'launch': 'hip-graph' if graphs else 'eager',
+        'config': {'launch': 'eager',
                    'workload': (f'BASELINE.json configs[{args.config - 1}]: {args.frames}-frame {lw * 8}x{lh * 8} clip, SD-1.5 UNet3D + '
-                                f'AnimateDiff motion modules, {args.ddim_steps}-step DDIM inversion (B=1) + '
-                                f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B=2), ' + ('the ranks share ONE clip per step' if longclip else 'one clip per GPU per step')
+                                f'AnimateDiff motion modules, {args.ddim_steps}-step DDIM inversion (B={cps}) + '
+                                f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B={2 * cps}), '
+                                + ('the ranks share ONE clip per step' if longclip else
+                                   f'{cps} clip{"s" if cps > 1 else ""} per GPU per step' + (' (denoised together: the batch axis of the latents)' if cps > 1 else ''))
                                 + ('; full swap path (VideoSwapPipeline.validation): AttentionStore during the inversion, '
                                    'ED-LoRA merge + per-layer text embeddings [2,16,77,768], point-adapter residuals for '
                                    'sampling steps 0-25, AttentionRefine + latent / self-attention SpatialBlenders '
                                    '(use_blend), weights restored' if swap else '')),
-                   'latents': [1, 4, args.frames, lh, lw],
+                   'latents': [cps, 4, args.frames, lh, lw],
                    'parallelism': (f'frame-sharded x{world} ({args.frames // world} frames per rank, exchange={args.exchange})'
                                    if longclip else f'clip-parallel x{world}')},
         'readings': {'R1e_frames_per_s': round(value, 4),
                      # R1s: the guided-sampling half alone (frames / device time of the 50 CFG steps)
                      'R1s_frames_per_s': round(frames_total / smp_s, 4) if smp_s > 0 else None,
-                     'inversion_s_per_clip': round(inv_s / max(args.steps, 1), 4),
-                     'sampling_s_per_clip': round(smp_s / max(args.steps, 1), 4),
+                     'inversion_s_per_clip': round(inv_s / per_clip, 4),
+                     'sampling_s_per_clip': round(smp_s / per_clip, 4),
                      'R2_unet_frame_evals_per_s': round(evals / elapsed, 2),
                      # FLOP the launches multiply; `..._reference_form` adds what the reference's formulation multiplies on top
                      # (nine taps on the upsampled image where the sub-pixel form of Upsample3D's convolution runs four)
@@ -399,12 +442,15 @@ def main():
                      'loop_mfma_frac': round(total_flop / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
                      'ceiling_R1e_at_100pct_mfma': 15.1},
     }
-    if longclip:
+    if distributed and world == 1:
+        out['config']['forced_distributed'] = 'VSX_FORCE_DISTRIBUTED=1: the multi-rank branches on one rank (%s)' % dist.get_backend()
+    if longclip and not stub:
         out['exchange'] = long_clip_exchange(pipe.unet, shard, args, world, lh, lw)
+    n_launch, gemm_ms, gemm_flop = roof['n'], roof['ms'], roof.get('flop', 0.0)
     if n_launch > 0 and gemm_ms > 0:
         ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
         traffic, traffic_alg, traffic_note = gemm_traffic(
-            args.frames, args.latent if (lh == lw == args.latent and args.config == 2) else -1)
+            args.frames, args.latent if (lh == lw == args.latent and args.config == 2 and cps == 1) else -1)
         traffic_ratio = round(traffic / traffic_alg, 3) if traffic and traffic_alg else None
         # footnote, not a roofline: what the power-managed clock sustains under chip-wide MFMA load on these boxes
         out['readings']['gemm_tflops_vs_sustained_clock_peak'] = {
@@ -415,14 +461,36 @@ def main():
                            'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_note,
                            'traffic_ratio': traffic_ratio, 'traffic_algorithmic': traffic_alg,
+                           # both rooflines per launch: a launch cannot finish before max(FLOP / 2.5 PF/s, algorithmic bytes /
+                           # 6.29 TB/s); the sum of those floors over the sampled launches / their measured time
+                           'frac_of_attainable': round(roof['floor_ms'] / gemm_ms, 4),
+                           'byte_bound_time_share': round(roof['byte_bound_ms'] / gemm_ms, 4),
+                           'byte_peak_TBps': HBM_COPY_TBPS,
+                           'algorithmic_GB_per_s': round(roof['bytes'] / (gemm_ms * 1e-3) / 1e9, 1),
                            'launches_sampled': int(n_launch), 'sample_stride': args.prof_stride,
-                           'sampling': ('all GEMM launches of every %d-th UNet call (eager); the other calls are '
-                                        'HIP-graph replays' % args.prof_stride) if graphs else
-                                       ('every %d-th GEMM launch' % args.prof_stride),
+                           'sampling': 'every %d-th GEMM launch' % args.prof_stride,
                            'avg_launch_us': round(1000.0 * gemm_ms / n_launch, 2),
                            'avg_launch_gflop': round(gemm_flop / n_launch / 1e9, 2),
                            'kernel_time_share_of_wall': round(gemm_ms * 1e-3 * args.prof_stride / (elapsed * 1.0), 4)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if (rank == 0 and world == 1 and cps == 1 and args.config == 2 and not args.no_batched_reading and not distributed
+            and device.type == 'cuda'):
+        # throughput mode as an extra reading (never `value`): TWO clips denoised together — UNet batch 2 in the inversion, 4
+        # under CFG — so that the small-M launches of the 16x16 / 8x8 levels and of the whole B = 1 half see twice the rows.
+        # One warm-up pair, one timed pair, same synthetic clips as above plus two more.
+        try:
+            extra = [synthetic_clip(seed=1000 * rank + 100 + i, frames=args.frames, height=lh, width=lw, device=device)
+                     for i in range(2)]
+            pair = [stack_clips(extra)]
+            run_clip(pair[0], args.ddim_steps)
+            t2 = timed_clips(run_clip, pair, args.ddim_steps, 1, barrier)
+            out['readings']['R1e_two_clips_per_step'] = {
+                'value': round(2 * args.frames / t2, 4), 'unit': 'frames/s', 'ms_per_step_of_two_clips': round(1e3 * t2, 1),
+                'gain_over_value': round(2 * args.frames / t2 / value, 4),
+                'note': 'latents [2,4,T,h,w]: inversion at UNet batch 2, CFG sampling at batch 4; a reading beside the headline '
+                        '(one clip per step), measured in this run after the timed region'}
+        except Exception as e:  # a reading must never take the headline down with it
+            out['readings']['R1e_two_clips_per_step'] = {'value': None, 'note': f'failed: {e!r}'}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and device.type == 'cuda':
         try:
             evals_per_s, threads, sample = cpu_baseline(args.cpu_frames, (lh, lw))
             out['cpu_baseline'] = {'value': round(evals_per_s / (3 * args.ddim_steps), 6), 'unit': 'frames/s',
@@ -432,7 +500,7 @@ def main():
             out['cpu_baseline'] = {'value': None, 'unit': 'frames/s', 'cores': torch.get_num_threads(),
                                    'kind': 'port', 'sample': f'failed: {e!r}'}
         try:
-            del pipe, clips
+            del pipe, clips, batches
             torch.cuda.empty_cache()
             pair_s = torch_rocm_baseline(device, args.frames, (lh, lw))
             out['torch_rocm_eager_fp16'] = {

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VSX_ABI_VERSION 9
+#define VSX_ABI_VERSION 10
 
 #define VSX_OK 0
 #define VSX_E_BADSHAPE (-1)
@@ -282,6 +282,13 @@ int vsx_prof_enable(int64_t on, int64_t max_samples);
 /* suspend (1) / resume (0) the sampling: events cannot be recorded while a stream is being captured into a HIP graph */
 int vsx_prof_pause(int64_t paused);
 int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* total_flop);
+/* ABI 10: the same collection priced against BOTH rooflines.  Per sampled launch the algorithmic bytes are A once + weights
+ * once + C once + residual once (a convolution reads every input pixel once); a launch cannot finish before
+ * max(FLOP / peak_flops, bytes / peak_bytes_per_s).  floor_ms = the sum of those floors over the sampled launches (so
+ * floor_ms / total_ms is the fraction of the ATTAINABLE rate the launch mix reached), byte_bound_ms = the measured time of the
+ * launches whose byte floor is the larger of the two.  Like vsx_prof_collect it consumes the samples. */
+int vsx_prof_collect_roofline(double peak_flops, double peak_bytes_per_s, int64_t* n_launches, double* total_ms,
+                              double* total_flop, double* total_bytes, double* floor_ms, double* byte_bound_ms);
 
 /* ------------------------------------------------------------------------------------------
  * RCCL collectives of the frame-sharded long-clip mode (the reference has no

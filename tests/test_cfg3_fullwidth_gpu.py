@@ -114,6 +114,7 @@ def test_cfg3_full_width_against_reference_controllers(size):
     e_out, e16_out = rel_l2(got, gold['final']), rel_l2(out16, gold['final'])
     _record(f'cfg3_T{size.frames}_64x64_{size.steps}+{size.steps}_steps', inversion_rel_l2=e_inv, inversion_rel_l2_fp16_oracle=e16_inv, final_rel_l2=e_out,
             final_rel_l2_fp16_oracle=e16_out, final_cosine=cosine(got, gold['final']),
+            final_cosine_fp16_oracle=cosine(out16, gold['final']),
             device_fp32_oracle_with_product_controllers_vs_golden=dict(inversion=e_pin_inv, final=e_pin),
             product_vs_fp16_oracle=rel_l2(got, out16), wall_s_product_validation=t_prod)
     assert torch.isfinite(got).all() and got.shape == gold['final'].shape
@@ -121,3 +122,9 @@ def test_cfg3_full_width_against_reference_controllers(size):
     assert e_pin_inv < 1e-4 and e_pin < 2e-3, (e_pin_inv, e_pin)
     assert e_inv <= 2 * e16_inv + 1e-4, f'inversion {e_inv:.3e} vs fp16-storage oracle {e16_inv:.3e}'
     assert e_out <= 2 * e16_out + 1e-4, f'final latents {e_out:.3e} vs fp16-storage oracle {e16_out:.3e}'
+    # round 5: cosine no worse than the yardstick's, the product within 1.5 x the yardstick's own error of
+    # the fp16-storage oracle, and an absolute cap on the final latents of the swap path (discrete controller decisions — mask
+    # thresholds, replaced maps — make this flow noisier than the plain loops: 1.4e-2 measured, 1.9e-2 for the yardstick)
+    assert cosine(got, gold['final']) >= cosine(out16, gold['final']) - 1e-4
+    assert rel_l2(got, out16) <= 1.5 * e16_out + 1e-4, (rel_l2(got, out16), e16_out)
+    assert e_out <= 3e-2 and e_inv <= 2e-2, (e_inv, e_out)

@@ -100,6 +100,14 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
         r = subprocess.run([exe, case], capture_output=True, text=True, timeout=600, env=env)
         print(r.stdout)
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    # round 5: the XCD block grid of the tile kernels (21: bit for bit like the linear walk, and actually chosen) and the residual
+    # prefetch behind the last slab with its exact vmcnt counts (22) — the latter also with every DMA piece landing as late as
+    # the kernel's own counted waits allow (an under-counted wait multiplies a slab that has not landed: the run fails)
+    for case, late in (('21', False), ('22', False), ('22', True), ('0', True), ('16', True)):
+        r = subprocess.run([exe, case], capture_output=True, text=True, timeout=900,
+                           env=dict(env, CPUHIP_DMA='late') if late else env)
+        print('late DMA' if late else '', r.stdout)
+        assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     for tile in ('1', '2', '3'):
         for case in ('0', '1', '4', '7', '8', '10', '17'):
             r = subprocess.run([exe, case], capture_output=True, text=True, timeout=600, env=dict(env, VSX_TUNE_TILE=tile))

@@ -368,3 +368,32 @@ def test_c_abi_allgathers_replayed_across_ranks(world):
     _replay(logs, part, allp)
     for r in range(world):
         assert torch.equal(allp[r], torch.stack(part))
+
+
+@pytest.mark.parametrize('config', [2, 4])
+def test_bench_plumbing_two_ranks_gloo(config, tmp_path):
+    """bench.py's own multi-rank code — process-group init, barriers, max-over-ranks, the whole-job metric arithmetic and the
+    ONE JSON line from rank 0 — launched the way the driver launches it (torch.distributed.run, 2 ranks), on CPU with gloo and
+    the clip loop stubbed (VSX_BENCH_STUB_CLIP=1: no model, no kernels).  The driver's first SCALE run must not be the first
+    execution of these lines; the same branches run on one MI355X rank with the real loop and the
+    nccl backend in tools/gpu_steps.sh dist1."""
+    import json
+    import subprocess
+    import sys
+    from util import ROOT
+    env = dict(os.environ, VSX_BENCH_STUB_CLIP='1', CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--config', str(config), '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, f'rank 0 prints ONE JSON line, got {len(lines)}'
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['higher_is_better'] is True
+    frames = 64 if config == 4 else 16
+    clips_job = 3 if config == 4 else 2 * 3          # the ranks share one long clip per step / every rank its own clips
+    assert out['scaling'] == ('strong' if config == 4 else 'weak')
+    assert abs(out['value'] - clips_job * frames / (out['ms_per_step'] * 3 / 1e3)) <= 0.02 * out['value']
+    assert out['ms_per_step'] >= 10.0                # the stub sleeps 10 ms per clip: the timed region really ran 3 steps
+    assert 'roofline' not in out and out['vs_baseline'] is None

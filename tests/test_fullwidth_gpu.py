@@ -86,16 +86,51 @@ def _fwd(model, x, t, txt, res=None):
     return out.float().cpu()
 
 
-def _check(name, prod_out, ref, half_out, extra=None):
+# Absolute caps (VERDICT round 4, next 5 iii): what the seeded synthetic weights have shown over four rounds is 1.3e-3 for one
+# forward and 0.8 - 1.0e-2 for the final latents of the loops; a product error several times that would still pass a rule that is
+# only relative to a yardstick, so the non-stress cases are also held to these.
+CAP_FORWARD = 3e-3
+CAP_FINAL_LATENTS = 2e-2
+
+
+def _check(name, prod_out, ref, half_out, extra=None, cap=CAP_FORWARD):
+    """The parity rule of one UNet forward.  Relative to the yardstick (the oracle with fp16 storage, against the same fp32
+    result): (a) rel-L2 <= 2 x yardstick, (b) no frame worse than 4 x, (c) cosine >= the yardstick's - 1e-4, (d) the product
+    stays within 1.5 x the yardstick's own error OF the fp16-storage oracle (two fp16 evaluations of the same network may differ
+    by about the root sum of squares of their errors, not by more); absolute: (e) rel-L2 <= `cap` (None for the stress cases,
+    whose yardstick is itself large)."""
     assert torch.isfinite(prod_out).all()
     e, e16 = rel_l2(prod_out, ref), rel_l2(half_out, ref)
     # per-frame check: no single frame (= one slab of M tiles) may hide behind the others
     B, C, T = ref.shape[:3]
     worst = max(rel_l2(prod_out[b, :, f], ref[b, :, f]) for b in range(B) for f in range(T))
-    _record(name, rel_l2=e, rel_l2_fp16_oracle=e16, cosine=cosine(prod_out, ref), worst_frame_rel_l2=worst,
-            **(extra or {}))
+    cos_p, cos_h = cosine(prod_out, ref), cosine(half_out, ref)
+    e_ph = rel_l2(prod_out, half_out)
+    _record(name, rel_l2=e, rel_l2_fp16_oracle=e16, cosine=cos_p, cosine_fp16_oracle=cos_h, worst_frame_rel_l2=worst,
+            product_vs_fp16_oracle_rel_l2=e_ph, **(extra or {}))
     assert e <= 2 * e16, f'{name}: rel-L2 {e:.3e} > 2 x fp16-storage oracle error {e16:.3e}'
     assert worst <= 4 * e16, f'{name}: worst frame rel-L2 {worst:.3e} vs fp16-storage oracle error {e16:.3e}'
+    assert cos_p >= cos_h - 1e-4, f'{name}: cosine {cos_p:.6f} below the fp16-storage oracle\'s {cos_h:.6f}'
+    assert e_ph <= 1.5 * e16, f'{name}: product vs fp16-storage oracle {e_ph:.3e} > 1.5 x that oracle\'s own error {e16:.3e}'
+    if cap is not None:
+        assert e <= cap, f'{name}: rel-L2 {e:.3e} above the absolute cap {cap:.1e}'
+
+
+def _check_loops(name, inv_p, out_p, inv_ref, out_ref, inv_h, out_h, extra=None):
+    """The same rule for the two loops: inverted latents and final latents, yardstick pushed through the same steps."""
+    assert torch.isfinite(out_p).all() and torch.isfinite(inv_p).all()
+    e_inv, e16_inv = rel_l2(inv_p, inv_ref), rel_l2(inv_h, inv_ref)
+    e_out, e16_out = rel_l2(out_p, out_ref), rel_l2(out_h, out_ref)
+    cos_p, cos_h = cosine(out_p, out_ref), cosine(out_h, out_ref)
+    e_ph = rel_l2(out_p, out_h)
+    _record(name, inversion_rel_l2=e_inv, inversion_rel_l2_fp16_oracle=e16_inv, final_rel_l2=e_out,
+            final_rel_l2_fp16_oracle=e16_out, final_cosine=cos_p, final_cosine_fp16_oracle=cos_h,
+            product_vs_fp16_oracle_rel_l2=e_ph, **(extra or {}))
+    assert e_inv <= 2 * e16_inv + 1e-4, f'{name}: inversion drift {e_inv:.3e} vs fp16-storage oracle {e16_inv:.3e}'
+    assert e_out <= 2 * e16_out + 1e-4, f'{name}: final-latent drift {e_out:.3e} vs fp16-storage oracle {e16_out:.3e}'
+    assert cos_p >= cos_h - 1e-4, f'{name}: final cosine {cos_p:.6f} below the fp16-storage oracle\'s {cos_h:.6f}'
+    assert e_ph <= 1.5 * e16_out + 1e-4, f'{name}: product vs fp16-storage oracle {e_ph:.3e} > 1.5 x its own error {e16_out:.3e}'
+    assert e_out <= CAP_FINAL_LATENTS and e_inv <= CAP_FINAL_LATENTS, f'{name}: {e_inv:.3e} / {e_out:.3e} above the absolute cap'
 
 
 def test_forward_vs_host_oracle(models):
@@ -158,13 +193,7 @@ def test_sequential_steps_448x768(models):
     inv_ref, out_ref = _oracle_loops(ora_dev, x, txt, neg, 3)
     inv_h, out_h = _oracle_loops(ora_h, x, txt, neg, 3)
     inv_p, out_p = _product_loops(prod, x, txt, neg, 3)
-    e_inv, e16_inv = rel_l2(inv_p, inv_ref), rel_l2(inv_h, inv_ref)
-    e_out, e16_out = rel_l2(out_p, out_ref), rel_l2(out_h, out_ref)
-    _record('loops_3+3_T8_56x96', inversion_rel_l2=e_inv, inversion_rel_l2_fp16_oracle=e16_inv, final_rel_l2=e_out,
-            final_rel_l2_fp16_oracle=e16_out, final_cosine=cosine(out_p, out_ref))
-    assert torch.isfinite(out_p).all()
-    assert e_inv <= 2 * e16_inv + 1e-4, f'inversion drift {e_inv:.3e} vs fp16-storage oracle {e16_inv:.3e}'
-    assert e_out <= 2 * e16_out + 1e-4, f'final-latent drift {e_out:.3e} vs fp16-storage oracle {e16_out:.3e}'
+    _check_loops('loops_3+3_T8_56x96', inv_p, out_p, inv_ref, out_ref, inv_h, out_h)
 
 
 def test_forward_edlora_text_and_adapter_residuals(models):
@@ -223,7 +252,7 @@ def test_forward_outlier_stress(models):
         ref = _fwd(ora_dev, x, 621, txt)
         out = _fwd(prod, x, 621, txt)
         _check('unet_B2_T4_64x64_outlier_stress', out, ref, _fwd(ora_h, x, 621, txt),
-               extra=dict(out_absmax=float(out.abs().max()), ref_absmax=float(ref.abs().max())))
+               extra=dict(out_absmax=float(out.abs().max()), ref_absmax=float(ref.abs().max())), cap=None)
     finally:
         with torch.no_grad():
             for p_, v in saved:
@@ -281,12 +310,79 @@ def test_sequential_steps_full_width(models, steps):
     e1.record()
     torch.cuda.synchronize()
     t_p, t_p_dev = time.time() - t0, e0.elapsed_time(e1) / 1e3
-    assert torch.isfinite(out_p).all()
-    e_inv, e16_inv = rel_l2(inv_p, inv_ref), rel_l2(inv_h, inv_ref)
-    e_out, e16_out = rel_l2(out_p, out_ref), rel_l2(out_h, out_ref)
-    _record(f'loops_{steps}+{steps}_T16_64x64', inversion_rel_l2=e_inv, inversion_rel_l2_fp16_oracle=e16_inv,
-            final_rel_l2=e_out, final_rel_l2_fp16_oracle=e16_out, final_cosine=cosine(out_p, out_ref),
-            final_cosine_fp16_oracle=cosine(out_h, out_ref), product_vs_fp16_oracle_rel_l2=rel_l2(out_p, out_h),
-            wall_s_product=t_p, device_s_product=t_p_dev, wall_s_fp32_torch_oracle=t_ref, wall_s_fp16_torch_oracle=t_h)
-    assert e_inv <= 2 * e16_inv + 1e-4, f'inversion drift {e_inv:.3e} vs fp16-storage oracle {e16_inv:.3e}'
-    assert e_out <= 2 * e16_out + 1e-4, f'final-latent drift {e_out:.3e} vs fp16-storage oracle {e16_out:.3e}'
+    _check_loops(f'loops_{steps}+{steps}_T16_64x64', inv_p, out_p, inv_ref, out_ref, inv_h, out_h,
+                 extra=dict(wall_s_product=t_p, device_s_product=t_p_dev, wall_s_fp32_torch_oracle=t_ref,
+                            wall_s_fp16_torch_oracle=t_h))
+
+
+def test_two_clips_per_step_match_the_oracle_clip_by_clip(models):
+    """(5c) bench.py's throughput reading denoises TWO clips together (latents [2,4,T,h,w]: UNet batch 2 in the inversion, 4
+    under CFG — the reference's own batch axis, pipeline_videoswap.py:478-550).  Every clip of the batch must obey the loop
+    rule against the oracle run on that clip ALONE: nothing may leak between the clips of a batch (GroupNorm pools per batch
+    item, the time-embedding row is shared, text rows are per item), and the larger M picks other kernels."""
+    cfg, ora, ora_dev, ora_h, prod = models
+    xs, txts, negs = [], [], []
+    for i in range(2):
+        x, txt = _inputs(1, 8, 64, 64, seed=151 + i)
+        xs.append(x); txts.append(txt)
+        negs.append(torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(17 + i)))
+    inv_p, out_p = _product_loops(prod, torch.cat(xs), torch.cat(txts), torch.cat(negs), 3)
+    assert inv_p.shape[0] == 2 and out_p.shape[0] == 2
+    for i in range(2):
+        inv_ref, out_ref = _oracle_loops(ora_dev, xs[i], txts[i], negs[i], 3)
+        inv_h, out_h = _oracle_loops(ora_h, xs[i], txts[i], negs[i], 3)
+        _check_loops(f'loops_3+3_T8_64x64_clip{i}_of_a_batch_of_2', inv_p[i:i + 1], out_p[i:i + 1], inv_ref, out_ref, inv_h, out_h)
+    assert not torch.equal(out_p[0], out_p[1])
+
+
+@torch.no_grad()
+def heavy_tailed_weights_(model, seed):
+    """A second synthetic weight family: the uniform fan-in family of `synth_weights_` gives well-behaved
+    activations, real checkpoints do not.  Every matrix / convolution weight is drawn from a Student-t with 3 degrees of freedom
+    (variance 3: scaled to the fan-in standard deviation of the uniform family; the tails put single weights 10 - 30 sigma out),
+    every normalisation gain log-uniformly in [0.05, 8] per channel, so that fp16 GEMM epilogues, the folded LayerNorm and the
+    fp16 residual stream see two orders of magnitude of dynamic range across channels."""
+    dev = next(model.parameters()).device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for name, p in model.named_parameters():
+        if p.dim() >= 2:
+            fan_in = p[0].numel()
+            # t(3) = normal / sqrt(chi2_3 / 3), from the seeded generator
+            z = torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32)
+            c = sum(torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) ** 2 for _ in range(3)) / 3.0
+            w = z / c.sqrt() * (1.0 / (3.0 * fan_in)) ** 0.5
+            if 'temporal_transformer.proj_out' in name:
+                w = w * 0.1
+            p.copy_(w.to(p.dtype))
+        elif 'norm' in name and name.endswith('weight'):
+            lo, hi = torch.log(torch.tensor(0.05)), torch.log(torch.tensor(8.0))
+            p.copy_(torch.exp(lo + (hi - lo) * torch.rand(p.shape, generator=g, device=dev)).to(p.dtype))
+        else:
+            p.copy_((torch.randn(p.shape, generator=g, device=dev) * 0.05).to(p.dtype))
+    return model
+
+
+def test_forward_heavy_tailed_weight_family():
+    """(6) one forward at B = 2, T = 4, 64x64 with Student-t(3) weights and per-channel gains over 0.05 ... 8, on its own models
+    (the shared fixture keeps the uniform family).  Same rule as every other forward except the absolute cap: this family's
+    yardstick is its own."""
+    from oracle import unet3d
+    from videoswap_amd.unet import AnimateDiffUNet3DModel
+    cfg = unet3d.full_config()
+    with torch.device('cuda'):
+        prod = AnimateDiffUNet3DModel(**cfg)
+        ora_dev = unet3d.AnimateDiffUNet3DModel(**cfg).eval()
+    prod = heavy_tailed_weights_(prod, seed=4321).half().eval()
+    ora_dev.load_state_dict({k: v.float() for k, v in prod.state_dict().items()}, strict=True)
+    ora_h = copy.deepcopy(ora_dev).half()
+    x, txt = _inputs(2, 4, 64, 64, seed=141)
+    ref = _fwd(ora_dev, x, 441, txt)
+    out = _fwd(prod, x, 441, txt)
+    half = _fwd(ora_h, x, 441, txt)
+    gains = torch.cat([p.detach().float().flatten() for n, p in prod.named_parameters() if 'norm' in n and n.endswith('weight')])
+    wmax = max(float(p.detach().float().abs().max() / p.detach().float().std()) for n, p in prod.named_parameters() if p.dim() >= 2)
+    _check('unet_B2_T4_64x64_heavy_tailed_weights', out, ref, half, cap=None,
+           extra=dict(out_absmax=float(out.abs().max()), ref_absmax=float(ref.abs().max()), gain_min=float(gains.min()),
+                      gain_max=float(gains.max()), largest_weight_in_sigmas=wmax))
+    del prod, ora_dev, ora_h
+    torch.cuda.empty_cache()

@@ -363,6 +363,31 @@ int main(int argc, char** argv) {
         n_bad += same && g_last_xcd_gm > 0 ? 0 : 1;
         vsx_set_option("tile_tune", 0);
     }
+    if (only < 0 || only == nplain + 9) {
+        // residual prefetch of the tile kernels BEHIND the last slab (gemm.hip, RES_LATE): ten slabs, every forced tile / ring
+        // depth; pp_sched bit 64 (issue in iteration 0, no exact count) must agree bit for bit.  Run it under CPUHIP_DMA=late as
+        // well: the counted waits then decide what has landed when a slab is multiplied.
+        struct T { const char* name; long tune; long M, N; };
+        const T tiles[] = {{"128x160 ring 2", 2, 200, 320}, {"128x160 ring 4", 2 + 16, 200, 320}, {"128x320", 1, 200, 640},
+                           {"128x128", 4, 200, 256}, {"64x128", 5, 100, 256}, {"64x64", 6, 100, 128}};
+        for (const T& t : tiles) {
+            char name[128];
+            snprintf(name, sizeof name, "late residual prefetch, %s tile: %ldx%ldx640 +res", t.name, t.M, t.N);
+            Plain c = {name, t.M, t.N, 640, true, false, false, false, false, 0, 0, 0, false};
+            vsx_set_option("tile_tune", t.tune);
+            vsx_set_option("pp_sched", 0);
+            rng_state = 4321u;
+            const auto a = run_plain(c, true);
+            vsx_set_option("pp_sched", 64);
+            rng_state = 4321u;
+            const auto b = run_plain(c, false);
+            const bool same = memcmp(a.data(), b.data(), a.size() * sizeof(half_t)) == 0;
+            printf("%-58s %s\n", "  ... bit-identical to the early placement", same ? "ok" : "FAIL");
+            n_bad += same ? 0 : 1;
+        }
+        vsx_set_option("tile_tune", 0);
+        vsx_set_option("pp_sched", 0);
+    }
     printf(n_bad ? "%d check(s) FAILED\n" : "all checks passed\n", n_bad);
     return n_bad ? 1 : 0;
 }

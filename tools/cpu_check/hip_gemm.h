@@ -53,9 +53,23 @@ static inline void cpuhip_land(unsigned char* dst, const unsigned char* src16) {
 static inline void cpuhip_wait_vmcnt(int n) {       // all but the n most recent pieces of this lane have landed
     const size_t keep = (size_t)n < cpuhip_queue.size() ? (size_t)n : cpuhip_queue.size();
     const size_t done = cpuhip_queue.size() - keep;
-    for (size_t i = 0; i < done; ++i) memcpy(cpuhip_queue[i].dst, cpuhip_queue[i].data, 16);
+    for (size_t i = 0; i < done; ++i)
+        if (cpuhip_queue[i].dst) memcpy(cpuhip_queue[i].dst, cpuhip_queue[i].data, 16);
     cpuhip_queue.erase(cpuhip_queue.begin(), cpuhip_queue.begin() + (long)done);
 }
+
+// Ordinary VGPR-destination loads share the vmcnt queue with the DMA pieces: a kernel that keeps such loads in flight across
+// counted slab waits (gemm.hip's residual prefetch behind the last slab) says so with VSX_VMEM_NOTE(n), and the late-landing
+// model queues n placeholders so that its counts match the hardware's.
+static inline void cpuhip_note_vmem(int n) {
+    if (!cpuhip_dma_late()) return;
+    for (int i = 0; i < n; ++i) {
+        cpuhip_pending p;
+        p.dst = nullptr;
+        cpuhip_queue.push_back(p);
+    }
+}
+#define VSX_VMEM_NOTE(n) cpuhip_note_vmem(n)
 
 template <typename LdsPtr>
 static inline void cpuhip_buffer_load_lds(cpuhip_rsrc r, LdsPtr lds, int size, int voffset, int soffset, int ioffset, int) {

@@ -38,7 +38,9 @@ def time_med(fn, reps=5, rounds=7):
 def main():
     print('# persistent kernel (gemm_pp = 2 forces it), tile kernel 256x320 (gemm_pp 0, tile_tune 3); median of 7 rounds x 5 launches')
     print(f'{"problem":44s} {"data":8s} {"kernel":12s} {"us":>9s} {"TF/s":>8s} {"of 2.5 PF":>9s}')
-    for (M, N, K) in ((4096, 4160, 4096), (8192, 8320, 8192), (8192, 8320, 2880), (131072, 320, 2880), (32768, 1280, 2560)):
+    # 4096 x 5120 and 8192 x 10240: 256 / 1024 tiles of 256 x 320 = 1 / 4 per CU (4160 / 8320 columns leave 208 / 832 tiles: 81 % of the
+    # CU-rounds busy — the first table of profiles/r05_gemm_square_calibration.txt)
+    for (M, N, K) in ((4096, 5120, 4096), (8192, 10240, 8192), (4096, 4160, 4096), (8192, 8320, 8192), (8192, 8320, 2880), (131072, 320, 2880), (32768, 1280, 2560)):
         for data in ('uniform', 'zeros'):
             if data == 'uniform':
                 x, w = uni(M, K), uni(N, K)

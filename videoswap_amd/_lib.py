@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 VARIANT = os.environ.get('VSX_LIB_VARIANT') or None
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvsx.so' if not VARIANT else f'libvsx_{VARIANT}.so')
 
-VSX_ABI_VERSION = 9
+VSX_ABI_VERSION = 10
 
 
 class VsxError(RuntimeError):
@@ -99,6 +99,8 @@ PROTOTYPES = {
     'vsx_allreduce_gnstats': (c_int, [c_void_p, c_int64, c_void_p]),
     'vsx_prof_pause': (c_int, [c_int64]),
     'vsx_prof_collect': (c_int, [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),
+    'vsx_prof_collect_roofline': (c_int, [c_double, c_double, POINTER(c_int64), POINTER(c_double), POINTER(c_double),
+                                          POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     # gradient path of the adapter training step (csrc/train.hip)
     'vsx_geglu_fwd': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'vsx_geglu_bwd': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

@@ -319,49 +319,64 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
     for (int s = 0; s < PREFETCH; ++s)
         if (s < nloc) issue(kt_begin + s, s);
 
-    // Residual prefetch (8-wave tiles only: the 16-wave tile has no registers to spare): the epilogue's residual
-    // quads are requested now, behind the first operand slabs, so their HBM latency hides under the main loop
-    // instead of stalling every wave at the end of a short K loop.
+    // Residual prefetch (<= 8-wave tiles only: the 16-wave tile has no registers to spare): the epilogue's residual quads are
+    // requested while the K loop runs, so their HBM latency hides under it instead of stalling every wave at the end of a short
+    // loop.  WHEN they are requested matters as much: vmcnt retires in issue order, so loads queued behind the first slabs make
+    // the first slab wait wait for them too — round 5's phase stamps (profiles/r05_gemm_tile_phase_timing.txt) showed a 128x160
+    // workgroup of `proj 1280->1280 +res` at M = 4096 spending 8.9 us between its entry and its first MFMA: all 256 workgroups
+    // were fetching their residual tiles (10.5 MB) from HBM in front of the first operand slab.  The loads now go out BEHIND
+    // the last slab's pieces (RES_LATE: full 32-column tiles with 16-byte accesses, an exact count of NRES loads per wave, rows
+    // past M clamped), and every slab wait after that point allows NRES more entries in flight.
     constexpr bool PRE_RES = SWAP && (NW <= 8) && (TM * TN <= 5);
+    constexpr int NRES = TM * TN * 2;
     h4 rpre[PRE_RES ? TM * TN * 4 : 1];
     const half_t* Rb0 = p.residual ? p.residual + z0 * p.r_bs0 + z1 * p.r_bs1 : nullptr;
     const bool pre_res = PRE_RES && Rb0 != nullptr && p.vec4 && !p.geglu && p.splitk <= 1;
-    if constexpr (PRE_RES) {
-        if (pre_res) {
+    const bool res_late = pre_res && p.rvec8 && (int)n0 + BN <= (int)p.N;
+    bool r_inflight = false;                        // the NRES residual loads sit behind every slab piece issued so far
+    auto issue_residual = [&]() {                   // exactly NRES 16-byte loads per wave (wave-uniform control flow)
+        if constexpr (PRE_RES) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int m = (int)m0 + wr * WM + i * 32 + l31;
+                const unsigned m = (unsigned)min((int)m0 + wr * WM + i * 32 + l31, (int)p.M - 1);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (p.rvec8 && (int)n0 + wc * WN + j * 32 + 31 < (int)p.N) {
-                        // full tile: two 16-byte loads in the epilogue's post-exchange layout (8 consecutive columns
-                        // per lane); the epilogue swaps them back into register-quad order
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            const int nc = (int)n0 + wc * WN + j * 32 + 16 * a + 8 * hi;
-                            uint4 v = make_uint4(0, 0, 0, 0);
-                            if (m < (int)p.M) v = *reinterpret_cast<const uint4*>(Rb0 + (unsigned)m * (unsigned)p.ldr + nc);
-                            rpre[(i * TN + j) * 4 + 2 * a] = __builtin_bit_cast(h4, make_uint2(v.x, v.y));
-                            rpre[(i * TN + j) * 4 + 2 * a + 1] = __builtin_bit_cast(h4, make_uint2(v.z, v.w));
-                        }
-                        continue;
+                    for (int a = 0; a < 2; ++a) {
+                        const int nc = (int)n0 + wc * WN + j * 32 + 16 * a + 8 * hi;
+                        const uint4 v = *reinterpret_cast<const uint4*>(Rb0 + m * (unsigned)p.ldr + nc);
+                        rpre[(i * TN + j) * 4 + 2 * a] = __builtin_bit_cast(h4, make_uint2(v.x, v.y));
+                        rpre[(i * TN + j) * 4 + 2 * a + 1] = __builtin_bit_cast(h4, make_uint2(v.z, v.w));
                     }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int nb = (int)n0 + wc * WN + j * 32 + 8 * g + 4 * hi;
-                        h4 v = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-                        if (m < (int)p.M && nb + 3 < (int)p.N)
-                            v = *reinterpret_cast<const h4*>(Rb0 + (unsigned)m * (unsigned)p.ldr + nb);
-                        rpre[(i * TN + j) * 4 + g] = v;
-                    }
-                }
             }
         }
-    }
-
-    // slab kt must have landed; later slabs (at most PREFETCH-1 of them) stay in flight
+    };
+    // ONE issue site, inside the K loop (a second one in front of the loop would make the compiler guard the registers against
+    // each other with a vmcnt(0)): iteration kt_r is the one whose first k-step sends the last pieces of the last slab; launches
+    // whose slabs are all in flight when the loop starts (nloc <= PREFETCH + 1) issue in iteration 0, and a single-slab launch
+    // (no loop iteration at all) reads its residual in the epilogue.  TILE_RES_EARLY: iteration 0 whatever the K length, without
+    // the exact count (the slab waits then wait for the residual as well: round 4's behaviour, for A/B runs).
+    const bool res_early = (p.pp_flags & TILE_RES_EARLY) != 0;
+    const int kt_r = res_early ? 0 : max(nloc - 1 - PREFETCH, 0);
+    bool r_loaded = false;
+    // slab kt must have landed; later slabs (at most PREFETCH-1 of them) stay in flight, and so do the residual loads once they
+    // have been issued behind the last slab (r_inflight)
     auto wait_slab = [&](const int kt) {
         const int later = min(nloc - 1 - kt, PREFETCH - 1);
+        if (PRE_RES && r_inflight) {
+            if (wave < N_HI) {
+                constexpr int G = GA + GB_HI;
+                if (PREFETCH >= 3 && later >= 2) wait_vmcnt<2 * G + NRES>();
+                else if (PREFETCH >= 2 && later == 1) wait_vmcnt<G + NRES>();
+                else wait_vmcnt<NRES>();
+            } else {
+                constexpr int G = GA + GB_LO;
+                if (PREFETCH >= 3 && later >= 2) wait_vmcnt<2 * G + NRES>();
+                else if (PREFETCH >= 2 && later == 1) wait_vmcnt<G + NRES>();
+                else wait_vmcnt<NRES>();
+            }
+            return;
+        }
         if (wave < N_HI) {
             constexpr int G = GA + GB_HI;
             if (PREFETCH >= 3 && later >= 2) wait_vmcnt<2 * G>();
@@ -441,6 +456,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
             __builtin_amdgcn_sched_barrier(0);
             mma_issue(af0, bf0, late);                    // (late waves: the slab prepared in the previous iteration)
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PRE_RES) {
+                if (res_late && kt == kt_r) {                     // every piece of every slab is out: the residual behind them
+                    issue_residual();
+                    VSX_VMEM_NOTE(NRES);
+                    r_inflight = !res_early;
+                    r_loaded = true;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             ldfrag(sb, offs[2], af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
             mma(af1, bf1);
@@ -649,7 +673,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
 #pragma unroll
                         for (int a = 0; a < 2; ++a) {
                             uint2 lo2, hi2;
-                            if (PRE_RES && pre_res) {
+                            if (PRE_RES && r_loaded) {
                                 lo2 = __builtin_bit_cast(uint2, rpre[PRE_RES ? (i * TN + j) * 4 + 2 * a : 0]);
                                 hi2 = __builtin_bit_cast(uint2, rpre[PRE_RES ? (i * TN + j) * 4 + 2 * a + 1 : 0]);
                             } else {
@@ -689,7 +713,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         if (rrow) {
                             h4 b;
                             if (p.rvec8) b = rq[g];
-                            else if (PRE_RES && pre_res) b = rpre[PRE_RES ? (i * TN + j) * 4 + g : 0];
+                            else if (PRE_RES && r_loaded) b = rpre[PRE_RES ? (i * TN + j) * 4 + g : 0];
                             else b = *reinterpret_cast<const h4*>(rrow + nb);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
@@ -739,7 +763,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         }
                         if (rrow) {
                             h4 b;
-                            if (PRE_RES && pre_res) b = rpre[PRE_RES ? (i * TN + j) * 4 + g : 0];
+                            if (PRE_RES && r_loaded) b = rpre[PRE_RES ? (i * TN + j) * 4 + g : 0];
                             else b = *reinterpret_cast<const h4*>(rrow + nb);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
@@ -918,6 +942,7 @@ int launch(GemmParams& p, long tiles_m, long nbatch, hipStream_t stream) {
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
+    p.pp_flags = (int)(gemm_option("pp_sched") & TILE_RES_EARLY);
     p.tiles_m = (int)tiles_m;
     p.xcd_gm = g_last_xcd_gm = plan_xcd_grid(p, tiles_m, BM, BN, nbatch);
     dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)(p.splitk > 1 ? p.splitk : nbatch));
@@ -951,6 +976,7 @@ struct ProfState {
     long n = 0;
     double flop = 0.0;
     std::vector<hipEvent_t>* ev = nullptr;  // 2 per sample
+    std::vector<double>* work = nullptr;    // 2 per sample: algorithmic FLOP, algorithmic bytes (vsx_prof_collect_roofline)
 };
 
 ProfState g_prof;
@@ -959,6 +985,8 @@ ProfState g_prof;
 
 extern "C" int vsx_prof_enable(int64_t on, int64_t max_samples) {
     if (!g_prof.ev) g_prof.ev = new std::vector<hipEvent_t>();
+    if (!g_prof.work) g_prof.work = new std::vector<double>();
+    g_prof.work->clear();
     g_prof.on = on != 0;
     g_prof.stride = on > 1 ? on : 1;        // on = k > 1: bracket every k-th launch only
     g_prof.seen = 0;
@@ -974,8 +1002,13 @@ extern "C" int vsx_prof_pause(int64_t paused) {
     return VSX_OK;
 }
 
-extern "C" int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* total_flop) {
-    double ms = 0.0;
+// Per sampled launch: duration t, algorithmic FLOP f and algorithmic bytes b (A once + weights once + C once + residual once; a
+// convolution reads every input pixel once).  A launch cannot finish before max(f / peak_flops, b / peak_bytes_per_s): the sum of
+// those floors over the samples is what the same launches would take on BOTH rooflines at once (`floor_ms`), and
+// `byte_bound_ms` is the measured time of the launches whose byte floor is the larger one.
+extern "C" int vsx_prof_collect_roofline(double peak_flops, double peak_bytes_per_s, int64_t* n_launches, double* total_ms,
+                                         double* total_flop, double* total_bytes, double* floor_ms, double* byte_bound_ms) {
+    double ms = 0.0, bytes = 0.0, floor = 0.0, bb = 0.0;
     if (g_prof.ev) {
         for (long i = 0; i < g_prof.n; ++i) {
             hipEvent_t a = (*g_prof.ev)[2 * i], b = (*g_prof.ev)[2 * i + 1];
@@ -983,14 +1016,29 @@ extern "C" int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* t
             float t = 0.f;
             if (hipEventElapsedTime(&t, a, b) != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "prof: elapsed failed");
             ms += t;
+            if (g_prof.work && (long)g_prof.work->size() >= 2 * (i + 1) && peak_flops > 0.0 && peak_bytes_per_s > 0.0) {
+                const double f = (*g_prof.work)[2 * i], by = (*g_prof.work)[2 * i + 1];
+                const double tf = f / peak_flops, tb = by / peak_bytes_per_s;
+                bytes += by;
+                floor += 1e3 * (tf > tb ? tf : tb);
+                if (tb > tf) bb += t;
+            }
         }
     }
     if (n_launches) *n_launches = g_prof.n;
     if (total_ms) *total_ms = ms;
     if (total_flop) *total_flop = g_prof.flop;
+    if (total_bytes) *total_bytes = bytes;
+    if (floor_ms) *floor_ms = floor;
+    if (byte_bound_ms) *byte_bound_ms = bb;
     g_prof.n = 0;
     g_prof.flop = 0.0;
+    if (g_prof.work) g_prof.work->clear();
     return VSX_OK;
+}
+
+extern "C" int vsx_prof_collect(int64_t* n_launches, double* total_ms, double* total_flop) {
+    return vsx_prof_collect_roofline(0.0, 0.0, n_launches, total_ms, total_flop, nullptr, nullptr, nullptr);
 }
 
 namespace vsxg {
@@ -1287,7 +1335,19 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
     if (sample) {
         (void)hipEventRecord(e1, stream);
         g_prof.n += 1;
-        g_prof.flop += 2.0 * (double)d->M * (double)cols * (double)p.K * (double)nbatch;      // (sub-pixel form: the 4 C it multiplies)
+        const double flop = 2.0 * (double)d->M * (double)cols * (double)p.K * (double)nbatch;      // (sub-pixel form: the 4 C it multiplies)
+        g_prof.flop += flop;
+        // algorithmic bytes (tools/pmc_by_shape.py has the same definition): every operand element once
+        double a_el = (double)d->M * (double)d->K;
+        if (p.a_mode == 1) {
+            const double nimg = (double)d->M / ((double)p.Ho * (double)p.Wo) / (p.sp_Mc > 0 ? 4.0 : 1.0);
+            const double hin = p.ups ? p.H / 2 : p.H, win = p.ups ? p.W / 2 : p.W;     // (sub-pixel form: p.H, p.W are the source's already)
+            a_el = nimg * hin * win * (double)(p.C1 + p.C2);
+        }
+        const double w_el = (double)cols * (double)d->K * (p.sp_Mc > 0 ? 4.0 : 1.0);
+        const double c_el = (double)d->M * (double)d->N;
+        g_prof.work->push_back(flop);
+        g_prof.work->push_back(2.0 * (double)nbatch * (a_el + w_el + c_el + (d->residual ? c_el : 0.0)));
     }
     return rc;
 }

@@ -66,8 +66,16 @@ constexpr int PP_CONV_ASHIFT_ON = 1 << 16;
 // The A (and, in the plain GEMMs, B) pieces of a slab are issued from a per-CU starting point (gemm_pp.hip, "PIECE ROTATION");
 // bit 32 restores the common order (A/B runs).
 constexpr int PP_COMMON_ORDER = 32;
+// Workgroup-per-tile kernels: bit 64 of the same option issues the residual prefetch in front of the K loop again (round 4's
+// placement; A/B runs).  Default: behind the last slab's pieces (gemm.hip, "RES_LATE").
+constexpr int TILE_RES_EARLY = 64;
 
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// tools/cpu_check: the host model of the vmcnt queue is told about ordinary loads that stay in flight across counted waits
+#ifndef VSX_VMEM_NOTE
+#define VSX_VMEM_NOTE(n) do { } while (0)
+#endif
 
 #ifdef __HIPCC__
 template <int N>

@@ -5,42 +5,51 @@
 
 namespace {
 
-constexpr int GN_STAT_THREADS = 512;
+constexpr int GN_MAX_THREADS = 512;
 constexpr int GN_MAX_GROUPS = 64;
 
-// rows per statistics chunk / per apply block: sized for ~2048 workgroups in total whatever the split between images
-// and rows (5-D GroupNorm: 2 images x 65536 rows; per-frame GroupNorm: 32 images x 4096 rows; 8x8 level: 1-4 K rows)
+// Thread layout of the statistics and the apply kernel: a row is vpr = C / 8 16-byte vectors, a workgroup has
+// rp = 512 / vpr (>= 1) rows in flight per pass and rp * vpr threads (480 for C = 320 ... 1920, 320 for C = 2560), so that a
+// thread keeps ONE column octet for its whole life: thread t owns vector t % vpr of rows t / vpr, t / vpr + rp, ...  The per-channel
+// constants of the apply kernel (scale / shift) therefore live in 16 registers per thread instead of an LDS table that every
+// vector read back (64 B of LDS reads per 16 B of HBM), and neither kernel divides anything inside its streaming loop.
+__host__ __device__ inline int gn_threads(int C) {
+    const int vpr = C >> 3;
+    return (GN_MAX_THREADS / vpr) * vpr;
+}
+
+// Rows per statistics chunk / per apply workgroup: ~3 (statistics) and ~4 (apply) workgroups per CU whatever the split between
+// images and rows (5-D GroupNorm: 2 images x 65536 rows; per-frame GroupNorm: 32 images x 4096 rows; 8x8 level: 1-4 K rows).
+// Round 4 launched 2048 workgroups of 64 rows: a 41-KB stream each, behind which the block reduction (statistics) or the
+// table build (apply) took about as long as the stream itself — 1.7 and 3.0 TB/s over a forward against the 5 TB/s of a copy.
 __host__ __device__ inline int gn_stat_rows(long rows, long nimg) {
-    long r = rows * nimg / 2048;
-    return (int)(r < 8 ? 8 : (r > 512 ? 512 : r));
+    long r = rows * nimg / 768;
+    return (int)(r < 8 ? 8 : (r > 1024 ? 1024 : r));
 }
 __host__ __device__ inline int gn_apply_rows(long rows, long nimg) {
-    long r = rows * nimg / 2048;
-    return (int)(r < 2 ? 2 : (r > 64 ? 64 : r));
+    long r = rows * nimg / 1024;
+    return (int)(r < 4 ? 4 : (r > 512 ? 512 : r));
 }
 
 // Per-thread partial sums of the statistics kernel in LDS: a thread owns 8 consecutive channels.  Scalar writes in channel order sit
-// at a pitch of 8 floats and use an eighth of the banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.75); channel c = 8 v + e is
-// kept at (e / 4) * C / 2 + 4 v + e % 4 instead, so that a thread writes two 16-byte quads and the low quads of all lanes are contiguous
-// (0.64: what is left comes from rows of 40 vectors wrapping inside the 16-lane groups of a b128 access).  Neither kernel is bound by
-// LDS (lds_issue_stall 0.01 - 0.06, both run at the rate of a device copy): the apply kernel keeps its channel-order tables — the
-// same remap there raised its ratio from 0.42 to 0.64 without changing its time (profiles/r03_pmc_sq_lds.txt).
+// at a pitch of 8 floats and use an eighth of the banks; channel c = 8 v + e is kept at (e / 4) * C / 2 + 4 v + e % 4 instead, so
+// that a thread writes two 16-byte quads and the low quads of all lanes are contiguous.
 __device__ __forceinline__ int gn_col(const int c, const int C) { return ((c >> 2) & 1) * (C >> 1) + (c >> 3) * 4 + (c & 3); }
 
-__device__ __forceinline__ uint4 gn_load(const half_t* x1, const half_t* x2, long row, int c, int C1, int C2) {
-    const half_t* ptr = (c < C1) ? x1 + row * C1 + c : x2 + row * C2 + (c - C1);     // one load, selected address
-    return ld16(ptr);
+__device__ __forceinline__ const half_t* gn_src(const half_t* x1, const half_t* x2, int c, int C1, int C2, long& pitch) {
+    pitch = c < C1 ? C1 : C2;                   // a thread's column octet lies in one of the two concatenated sources
+    return c < C1 ? x1 + c : x2 + (c - C1);
 }
 
-// grid (nchunks, nimg), block 512.
-__global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t* __restrict__ x1,
-                                                                   const half_t* __restrict__ x2, long rows, int C1,
-                                                                   int C2, int groups, float* __restrict__ partial) {
+// grid (nchunks, nimg), block gn_threads(C).
+__global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(const half_t* __restrict__ x1,
+                                                                  const half_t* __restrict__ x2, long rows, int C1,
+                                                                  int C2, int groups, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float red_s[4096];
     __shared__ __attribute__((aligned(16))) float red_q[4096];
     const int C = C1 + C2;
     const int vpr = C >> 3;                   // vectors per row (<= 512)
-    const int rp = GN_STAT_THREADS / vpr;      // rows per pass (>= 1)
+    const int rp = (int)blockDim.x / vpr;     // rows per pass (>= 1): every thread of the block has a row
     const int tid = threadIdx.x;
     const int rl = tid / vpr;
     const int cv = tid - rl * vpr;
@@ -49,39 +58,38 @@ __global__ __launch_bounds__(GN_STAT_THREADS) void gn_stats_kernel(const half_t*
     const int rpc = gn_stat_rows(rows, gridDim.y);
     const long r0 = (long)chunk * rpc;
     const long r1 = min(r0 + (long)rpc, rows);
+    long pitch;
+    const half_t* src = gn_src(x1, x2, cv * 8, C1, C2, pitch) + img * rows * pitch;
 
     float s[8], q[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    if (rl < rp) {
-        // four row loads in flight per thread (the loop used to wait for each load before issuing the next)
-        for (long rb = r0 + rl; rb < r1; rb += 4 * rp) {
-            uint4 raw[4];
+    // eight row loads in flight per thread
+    for (long rb = r0 + rl; rb < r1; rb += 8 * rp) {
+        uint4 raw[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long r = rb + u * rp;
-                raw[u] = r < r1 ? gn_load(x1, x2, img * rows + r, cv * 8, C1, C2) : make_uint4(0, 0, 0, 0);
-            }
+        for (int u = 0; u < 8; ++u) {
+            const long r = rb + u * rp;
+            raw[u] = r < r1 ? ld16(src + r * pitch) : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const h8 v = as_h8(raw[u]);
+        for (int u = 0; u < 8; ++u) {
+            const h8 v = as_h8(raw[u]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    s[e] += f;
-                    q[e] += f * f;
-                }
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                s[e] += f;
+                q[e] += f * f;
             }
         }
-        // a thread's 8 channels go out as two 16-byte writes, the low quads of a row's threads contiguous, then the high quads
-        // (scalar writes at a pitch of 8 floats hit 4 of the 32 banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.75)
-        *reinterpret_cast<f4v*>(red_s + rl * C + cv * 4) = f4v{s[0], s[1], s[2], s[3]};
-        *reinterpret_cast<f4v*>(red_s + rl * C + (C >> 1) + cv * 4) = f4v{s[4], s[5], s[6], s[7]};
-        *reinterpret_cast<f4v*>(red_q + rl * C + cv * 4) = f4v{q[0], q[1], q[2], q[3]};
-        *reinterpret_cast<f4v*>(red_q + rl * C + (C >> 1) + cv * 4) = f4v{q[4], q[5], q[6], q[7]};
     }
+    // a thread's 8 channels go out as two 16-byte writes, the low quads of a row's threads contiguous, then the high quads
+    *reinterpret_cast<f4v*>(red_s + rl * C + cv * 4) = f4v{s[0], s[1], s[2], s[3]};
+    *reinterpret_cast<f4v*>(red_s + rl * C + (C >> 1) + cv * 4) = f4v{s[4], s[5], s[6], s[7]};
+    *reinterpret_cast<f4v*>(red_q + rl * C + cv * 4) = f4v{q[0], q[1], q[2], q[3]};
+    *reinterpret_cast<f4v*>(red_q + rl * C + (C >> 1) + cv * 4) = f4v{q[4], q[5], q[6], q[7]};
     __syncthreads();
-    for (int c = tid; c < C; c += GN_STAT_THREADS) {
+    for (int c = tid; c < C; c += (int)blockDim.x) {
         const int col = gn_col(c, C);           // the column sum stays in its (permuted) column of row 0
         float a = 0.f, b = 0.f;
         for (int r = 0; r < rp; ++r) { a += red_s[r * C + col]; b += red_q[r * C + col]; }
@@ -134,73 +142,64 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
-// grid (ceil(rows / gn_apply_rows(rows)), nimg), block 256.  Per-channel scale/shift (a = rstd*gamma,
-// b = beta - mean*a) are built once per workgroup in LDS, so the streaming loop is one FMA (+ SiLU) per element —
-// the first version recomputed the group index with an integer division per element and was VALU-bound.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2,
-                                                       long rows, int C1, int C2, int groups,
-                                                       const float* __restrict__ stats,
-                                                       const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
-                                                       int silu, half_t* __restrict__ y) {
-    __shared__ float s_mean[GN_MAX_GROUPS];
-    __shared__ float s_rstd[GN_MAX_GROUPS];
-    __shared__ __attribute__((aligned(16))) float s_a[4096];
-    __shared__ __attribute__((aligned(16))) float s_b[4096];
+// grid (ceil(rows / gn_apply_rows(rows)), nimg), block gn_threads(C).  Per-channel scale / shift (a = rstd * gamma,
+// b = beta - mean * a) of the thread's own eight channels are built once, in registers, so the streaming loop is one FMA
+// (+ SiLU) per element and touches no LDS (the first version recomputed the group index with an integer division per element
+// and was VALU-bound; the second kept the constants in an LDS table and read 64 bytes of it per 16-byte vector).
+__global__ __launch_bounds__(GN_MAX_THREADS) void gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2,
+                                                                  long rows, int C1, int C2, int groups,
+                                                                  const float* __restrict__ stats,
+                                                                  const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                                  int silu, half_t* __restrict__ y) {
     const int C = C1 + C2;
     const int cpg = C / groups;
-    const int tid = threadIdx.x;
-    const long img = blockIdx.y;
-    if (tid < groups) {
-        s_mean[tid] = stats[(img * groups + tid) * 2];
-        s_rstd[tid] = stats[(img * groups + tid) * 2 + 1];
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const int g = c / cpg;
-        const float a = s_rstd[g] * (float)gamma[c];
-        s_a[c] = a;
-        s_b[c] = (float)beta[c] - s_mean[g] * a;
-    }
-    __syncthreads();
     const int vpr = C >> 3;
+    const int rp = (int)blockDim.x / vpr;
+    const int tid = threadIdx.x;
+    const int rl = tid / vpr;
+    const int c0 = (tid - rl * vpr) * 8;
+    const long img = blockIdx.y;
+    float ca[8], cb[8];
+    {
+        const h8 gm = as_h8(ld16(gamma + c0)), bt = as_h8(ld16(beta + c0));
+        const float* st = stats + img * groups * 2;
+        int g = c0 / cpg, left = (g + 1) * cpg - c0;      // channels of group g from c0 on
+        float mean = st[2 * g], rstd = st[2 * g + 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (left == 0) { ++g; left = cpg; mean = st[2 * g]; rstd = st[2 * g + 1]; }
+            --left;
+            ca[e] = rstd * (float)gm[e];
+            cb[e] = (float)bt[e] - mean * ca[e];
+        }
+    }
+    long pitch;
+    const half_t* src = gn_src(x1, x2, c0, C1, C2, pitch) + img * rows * pitch;
+    half_t* dst = y + img * rows * C + c0;
     const int rpb = gn_apply_rows(rows, gridDim.y);
     const long r0 = (long)blockIdx.x * rpb;
-    const int nrow = (int)min((long)rpb, rows - r0);
-    const int nvec = nrow * vpr;
-    // vpr and 256 are both multiples of 8, or the column of a thread simply walks: recompute it cheaply per step
-    int r = tid / vpr, cv = tid - r * vpr;
-    const int dr = 256 / vpr, dc = 256 - dr * vpr;
+    const long r1 = min(r0 + (long)rpb, rows);
     // four vectors in flight per thread: all loads of a batch are issued before the first is used
-    for (int i0 = tid; i0 < nvec; i0 += 1024) {
+    for (long rb = r0 + rl; rb < r1; rb += 4 * rp) {
         uint4 raw[4];
-        int cs[4];
-        long rws[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            cs[u] = cv * 8;
-            rws[u] = img * rows + r0 + r;
-            raw[u] = (i0 + u * 256 < nvec) ? gn_load(x1, x2, rws[u], cs[u], C1, C2) : make_uint4(0, 0, 0, 0);
-            r += dr;
-            cv += dc;
-            if (cv >= vpr) { cv -= vpr; ++r; }
+            const long r = rb + u * rp;
+            raw[u] = r < r1 ? ld16(src + r * pitch) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u * 256 >= nvec) break;
-            const int c = cs[u];
+            const long r = rb + u * rp;
+            if (r >= r1) break;
             const h8 v = as_h8(raw[u]);
-            const f4v a0 = *reinterpret_cast<const f4v*>(s_a + c), a1 = *reinterpret_cast<const f4v*>(s_a + c + 4);
-            const f4v b0 = *reinterpret_cast<const f4v*>(s_b + c), b1 = *reinterpret_cast<const f4v*>(s_b + c + 4);
             h8 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float f0 = __builtin_fmaf((float)v[e], a0[e], b0[e]);
-                float f1 = __builtin_fmaf((float)v[e + 4], a1[e], b1[e]);
-                if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
-                o[e] = (half_t)f0;
-                o[e + 4] = (half_t)f1;
+            for (int e = 0; e < 8; ++e) {
+                float f = __builtin_fmaf((float)v[e], ca[e], cb[e]);
+                if (silu) f = silu_f(f);
+                o[e] = (half_t)f;
             }
-            st16(y + rws[u] * C + c, as_u4(o));
+            st16(dst + r * C, as_u4(o));
         }
     }
 }
@@ -413,7 +412,7 @@ extern "C" int vsx_groupnorm_stats(const void* x1, const void* x2, int64_t nimg,
     if (rc) return rc;
     VSX_REQUIRE(partial != nullptr, VSX_E_WORKSPACE, "groupnorm_stats: null partial buffer");
     dim3 grid((unsigned)vsx_groupnorm_chunks(rows, nimg), (unsigned)nimg);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_STAT_THREADS), 0, (hipStream_t)stream, (const half_t*)x1,
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3((unsigned)gn_threads((int)(C1 + C2))), 0, (hipStream_t)stream, (const half_t*)x1,
                        (const half_t*)x2, (long)rows, (int)C1, (int)C2, (int)groups, partial);
     return vsx_check_launch("vsx_groupnorm_stats");
 }
@@ -434,7 +433,7 @@ extern "C" int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg,
                        (int)nchunks, (int)groups, inv_count, eps, stats);
     const int rpb = gn_apply_rows(rows, nimg);
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nimg);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3((unsigned)gn_threads((int)C)), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
                        (long)rows, (int)C1, (int)C2, (int)groups, stats, (const half_t*)gamma, (const half_t*)beta,
                        (int)silu, (half_t*)y);
     return vsx_check_launch("vsx_groupnorm_apply");

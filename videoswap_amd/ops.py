@@ -754,6 +754,15 @@ def prof_enable(on, max_samples=4096, stride=1):
     check(_lib.load().vsx_prof_enable((max(int(stride), 1) if on else 0), max_samples), 'vsx_prof_enable')
 
 
+def prof_collect_roofline(peak_flops, peak_bytes_per_s):
+    """-> dict(n, ms, flop, bytes, floor_ms, byte_bound_ms) over the sampled launches (include/vsx.h: vsx_prof_collect_roofline)"""
+    n = ctypes.c_int64(0)
+    v = [ctypes.c_double(0) for _ in range(5)]
+    check(_lib.load().vsx_prof_collect_roofline(float(peak_flops), float(peak_bytes_per_s), ctypes.byref(n),
+                                                *[ctypes.byref(x) for x in v]), 'vsx_prof_collect_roofline')
+    return dict(n=n.value, ms=v[0].value, flop=v[1].value, bytes=v[2].value, floor_ms=v[3].value, byte_bound_ms=v[4].value)
+
+
 def prof_collect():
     n = ctypes.c_int64(0)
     ms = ctypes.c_double(0)
@@ -936,7 +945,7 @@ _ACTIVATIONS = {
     'unpack_latents': ((0,), ()), 'cfg_ddim_step': ((0, 1, 2), ()), 'masked_blend': ((0, 1), ()),
     'adapter_scatter': ((2,), ()),
 }
-_PLAIN = ('gemm', 'set_option', 'prof_pause', 'prof_enable', 'prof_collect', 'geglu_fwd', 'geglu_bwd', 'silu_bwd',
+_PLAIN = ('gemm', 'set_option', 'prof_pause', 'prof_enable', 'prof_collect', 'prof_collect_roofline', 'geglu_fwd', 'geglu_bwd', 'silu_bwd',
           'group_norm_bwd', 'layer_norm_bwd', 'softmax_bwd', 'sum_pool2x2', 'adapter_gather', 'attention_lse',
           'attention_bwd', 'attention_bwd_supported')
 
