@@ -13,6 +13,10 @@
 #   pytest         the whole -m gpu suite
 #   bench          python bench.py             (default line, both baseline legs)
 #   benchq         python bench.py --no-cpu-baseline --steps 2 --warmup 1
+#   benchcfg3      python bench.py --config 3 ...   (configs[2]: the full swap path)
+#   bench448       python bench.py --latent-h 56 --latent-w 96 ...   (448x768 frames: 26 of the 30 reference option files)
+#   bench2         python bench.py --clips-per-step 2 ...   (two clips denoised together)
+#   smoke          __graft_entry__.smoke()
 #   trace          rocprofv3 --kernel-trace --stats of a 10 + 10-step clip -> TAG_kernel_stats.txt
 #   pmcshape       tools/pmc_by_shape.sh       per-shape fabric traffic (also refreshes profiles/gemm_hbm_traffic.json)
 #   pmcsq          tools/pmc_sq.sh             SQ counters (MFMA busy, LDS conflicts)
@@ -62,6 +66,14 @@ for STEP in "$@"; do
       timeout 500 python bench.py > $O/${TAG}_bench.txt 2>&1; show bench 1 3500 ;;
     benchq)
       timeout 400 python bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/${TAG}_benchq.txt 2>&1; show benchq 1 3500 ;;
+    benchcfg3)
+      timeout 400 python bench.py --config 3 --steps 1 --warmup 1 --no-cpu-baseline > $O/${TAG}_benchcfg3.txt 2>&1; show benchcfg3 1 600 ;;
+    bench448)
+      timeout 400 python bench.py --latent-h 56 --latent-w 96 --steps 1 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench448.txt 2>&1; show bench448 1 600 ;;
+    bench2)
+      timeout 400 python bench.py --clips-per-step 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench2.txt 2>&1; show bench2 1 1500 ;;
+    smoke)
+      timeout 400 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${TAG}_smoke.txt 2>&1; show smoke 3 ;;
     trace)
       ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -o r05 -- python $R/bench.py --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --prof-samples 0 > $O/${TAG}_prof.log 2>&1 )
       DB=$(find $O/${TAG}_prof -name '*.db' | head -n 1)
