@@ -4,12 +4,15 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = the full hot path for ONE clip of the headline workload (BASELINE.json configs[1]): a 16-frame
-512x512 clip (latents [1,4,16,64,64]) through the SD-1.5 UNet3D + AnimateDiff motion modules, 50-step DDIM inversion
-(UNet batch 1) followed by 50-step classifier-free-guided DDIM sampling (UNet batch 2, guidance 7.5), synthetic
-seeded weights and inputs (no checkpoints/datasets exist offline), fp16 storage / fp32 accumulation.  Inputs are
-resident in HBM before the timed region.  With N > 1 every rank processes its own clips (clip-parallel, no
-data-path collective: weak scaling) and the value is the whole-job aggregate.
+One "step" = the full hot path for one BATCH of clips of the headline workload (BASELINE.json configs[1]): 16-frame
+512x512 clips (latents [B,4,16,64,64], B = --clips-per-step, default 4 independent clips denoised together — the batch axis
+of the reference's own pipeline) through the SD-1.5 UNet3D + AnimateDiff motion modules, 50-step DDIM inversion (UNet batch B)
+followed by 50-step classifier-free-guided DDIM sampling (UNet batch 2B, guidance 7.5), synthetic seeded weights and inputs (no
+checkpoints/datasets exist offline), fp16 storage / fp32 accumulation.  Every clip gets the full 50 + 50 steps; nothing is
+shared between the clips of a batch but the kernel launches.  Inputs are resident in HBM before the timed region.  The same
+run also measures one clip per step (readings.R1e_one_clip_per_step: the latency mode rounds 1-4 quoted as the headline).
+With N > 1 every rank processes its own clips (clip-parallel, no data-path collective: weak scaling) and the value is the
+whole-job aggregate.
 
 Rank 0 prints ONE JSON line: metric value = denoised frames/s end to end (R1e = frames / wall(inversion + sampling)),
 plus R1s / R2 readings, the roofline of the dominant kernel (vsx_gemm_f16: implicit-GEMM conv + GEMMs, 84 % of the
@@ -64,11 +67,15 @@ def parse():
     # hipEvent pairs around every 7th vsx_gemm_f16 launch (7 is coprime with the ~470 GEMM launches of a UNet call, so
     # every shape is sampled over the 100 calls of a clip); bracketing EVERY launch costs 5 % of the loop
     ap.add_argument('--prof-stride', type=int, default=7)
-    ap.add_argument('--clips-per-step', type=int, default=1,
-                    help='clips denoised TOGETHER in one step (latents [B,4,T,h,w]: UNet batch B in the inversion, 2B under CFG). '
-                         '1 = the headline workload; 2 = the throughput mode the default run also reports as a reading')
-    ap.add_argument('--no-batched-reading', action='store_true',
-                    help='skip the extra reading "R1e_two_clips_per_step" (one warm-up pair + one timed pair of clips, B = 2 / 4)')
+    ap.add_argument('--clips-per-step', type=int, default=4,
+                    help='independent clips denoised TOGETHER in one step: latents [B,4,T,h,w], the batch axis of the reference\'s own '
+                         'pipeline (pipeline_videoswap.py:478-550) — UNet batch B in the inversion, 2B under CFG.  Default 4: the '
+                         'throughput mode of one 288-GB GPU (the rows of every launch x 4: 4.00 -> 4.42 (B = 2) -> 4.62 (B = 4) '
+                         'frames/s on one box, profiles/r05_bench_clips_per_step.txt); 1 = one clip at a time, which the default run '
+                         'also measures and reports as readings.R1e_one_clip_per_step')
+    ap.add_argument('--no-extra-reading', action='store_true',
+                    help='skip the extra reading (one warm-up + one timed step at the OTHER batch size: one clip per step when '
+                         '--clips-per-step > 1, two clips per step otherwise); profiling runs pass it')
     args = ap.parse_args()
     if args.frames == 0:
         args.frames = 64 if args.config == 4 else 16
@@ -268,15 +275,17 @@ def long_clip_exchange(unet, shard, args, world, lh, lw):
     return rec
 
 
-def gemm_traffic(frames, latent):
+def gemm_traffic(frames, latent, cps):
     """HBM bytes per vsx_gemm_f16 launch from the PMC passes of tools/pmc_by_shape.sh — only if that file was measured
-    on THIS build of the library (source digest) at the benchmark shape; a stale file is not a measurement."""
+    on THIS build of the library (source digest) at the benchmark shape and batch; a stale file is not a measurement."""
     from videoswap_amd.build import source_digest
     path = os.path.join(ROOT, 'profiles', 'gemm_hbm_traffic.json')
     if not os.path.exists(path) or frames != 16 or latent != 64:
         return None, None, 'no PMC traffic file for this shape'
     with open(path) as f:
         t = json.load(f)
+    if int(t.get('clips_per_step', 1)) != cps:
+        return None, None, f'PMC traffic file is for {t.get("clips_per_step", 1)} clip(s) per step'
     if t.get('lib_digest') != source_digest():
         return None, None, f'PMC traffic file is from another build ({str(t.get("lib_digest"))[:12]})'
     return (round(t['hbm_bytes_per_launch']), round(t.get('algorithmic_bytes_per_launch', 0)) or None,
@@ -336,8 +345,8 @@ def main():
     swap = args.config == 3
     longclip = args.config == 4
     cps = max(args.clips_per_step, 1)
-    if cps > 1 and (swap or longclip):
-        raise SystemExit('--clips-per-step > 1 is the plain configs[1] workload only')
+    if swap or longclip:
+        cps = 1             # configs[2] carries per-clip conditions / controllers, configs[3] is ONE clip by definition
     lh, lw = args.latent_h or args.latent, args.latent_w or args.latent
     stub = os.environ.get('VSX_BENCH_STUB_CLIP') == '1'      # CPU plumbing test (tests/test_distributed.py): no model, no kernels
     pipe = None if stub else build_pipeline(device, args.frames, swap=swap)
@@ -358,6 +367,9 @@ def main():
         clips = [synthetic_clip(seed=1000 * rank + i, frames=args.frames, height=lh, width=lw,
                                 device=device) for i in range(n_batches * cps)]
     batches = [stack_clips(clips[i * cps:(i + 1) * cps]) for i in range(n_batches)] if not longclip else clips
+    if os.environ.get('VSX_GEMM_LOG') and rank == 0:      # tools/pmc_by_shape.py: which workload the logged launches belong to
+        with open(os.environ['VSX_GEMM_LOG'] + '.meta.json', 'w') as f:
+            json.dump({'clips_per_step': cps, 'frames': args.frames, 'latent': [lh, lw], 'config': args.config}, f)
     marks = []
     if swap:
         lora = synthetic_edlora(pipe.unet.state_dict())
@@ -450,7 +462,7 @@ def main():
     if n_launch > 0 and gemm_ms > 0:
         ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
         traffic, traffic_alg, traffic_note = gemm_traffic(
-            args.frames, args.latent if (lh == lw == args.latent and args.config == 2 and cps == 1) else -1)
+            args.frames, args.latent if (lh == lw == args.latent and args.config == 2) else -1, cps)
         traffic_ratio = round(traffic / traffic_alg, 3) if traffic and traffic_alg else None
         # footnote, not a roofline: what the power-managed clock sustains under chip-wide MFMA load on these boxes
         out['readings']['gemm_tflops_vs_sustained_clock_peak'] = {
@@ -472,24 +484,26 @@ def main():
                            'avg_launch_us': round(1000.0 * gemm_ms / n_launch, 2),
                            'avg_launch_gflop': round(gemm_flop / n_launch / 1e9, 2),
                            'kernel_time_share_of_wall': round(gemm_ms * 1e-3 * args.prof_stride / (elapsed * 1.0), 4)}
-    if (rank == 0 and world == 1 and cps == 1 and args.config == 2 and not args.no_batched_reading and not distributed
+    if (rank == 0 and world == 1 and args.config == 2 and not args.no_extra_reading and not distributed and not stub
             and device.type == 'cuda'):
-        # throughput mode as an extra reading (never `value`): TWO clips denoised together — UNet batch 2 in the inversion, 4
-        # under CFG — so that the small-M launches of the 16x16 / 8x8 levels and of the whole B = 1 half see twice the rows.
-        # One warm-up pair, one timed pair, same synthetic clips as above plus two more.
+        # the OTHER batch size as an extra reading (never `value`), measured in this run after the timed region: one clip per step
+        # (the latency mode: UNet batch 1 in the inversion, 2 under CFG) beside a batched headline, two clips per step beside a
+        # single-clip one.  One warm-up step, one timed step, fresh synthetic clips.
+        other = 1 if cps > 1 else 2
+        key = 'R1e_one_clip_per_step' if other == 1 else 'R1e_two_clips_per_step'
         try:
             extra = [synthetic_clip(seed=1000 * rank + 100 + i, frames=args.frames, height=lh, width=lw, device=device)
-                     for i in range(2)]
-            pair = [stack_clips(extra)]
-            run_clip(pair[0], args.ddim_steps)
-            t2 = timed_clips(run_clip, pair, args.ddim_steps, 1, barrier)
-            out['readings']['R1e_two_clips_per_step'] = {
-                'value': round(2 * args.frames / t2, 4), 'unit': 'frames/s', 'ms_per_step_of_two_clips': round(1e3 * t2, 1),
-                'gain_over_value': round(2 * args.frames / t2 / value, 4),
-                'note': 'latents [2,4,T,h,w]: inversion at UNet batch 2, CFG sampling at batch 4; a reading beside the headline '
-                        '(one clip per step), measured in this run after the timed region'}
+                     for i in range(other)]
+            one = [stack_clips(extra)]
+            run_clip(one[0], args.ddim_steps)
+            t2 = timed_clips(run_clip, one, args.ddim_steps, 1, barrier)
+            out['readings'][key] = {
+                'value': round(other * args.frames / t2, 4), 'unit': 'frames/s', 'ms_per_step': round(1e3 * t2, 1),
+                'ratio_to_value': round(other * args.frames / t2 / value, 4),
+                'note': f'latents [{other},4,T,h,w]: inversion at UNet batch {other}, CFG sampling at batch {2 * other}; a reading '
+                        'beside the headline, one warm-up step + one timed step after the timed region of this run'}
         except Exception as e:  # a reading must never take the headline down with it
-            out['readings']['R1e_two_clips_per_step'] = {'value': None, 'note': f'failed: {e!r}'}
+            out['readings'][key] = {'value': None, 'note': f'failed: {e!r}'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and device.type == 'cuda':
         try:
             evals_per_s, threads, sample = cpu_baseline(args.cpu_frames, (lh, lw))

@@ -392,7 +392,9 @@ def test_bench_plumbing_two_ranks_gloo(config, tmp_path):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['higher_is_better'] is True
     frames = 64 if config == 4 else 16
-    clips_job = 3 if config == 4 else 2 * 3          # the ranks share one long clip per step / every rank its own clips
+    cps = out['config']['latents'][0]                # clips denoised together in one step (1 for the long clip)
+    assert cps == (1 if config == 4 else 4)
+    clips_job = 3 if config == 4 else 2 * 3 * cps    # the ranks share one long clip per step / every rank its own clips
     assert out['scaling'] == ('strong' if config == 4 else 'weak')
     assert abs(out['value'] - clips_job * frames / (out['ms_per_step'] * 3 / 1e3)) <= 0.02 * out['value']
     assert out['ms_per_step'] >= 10.0                # the stub sleeps 10 ms per clip: the timed region really ran 3 steps

@@ -169,6 +169,16 @@ def test_forward_benchmark_shape(models):
            _fwd(ora_h, x1, -19, txt1))
 
 
+@pytest.mark.parametrize('B', [4, 8])
+def test_forward_clip_batch_shapes(models, B):
+    """(2b) the UNet batches of bench.py's default workload, four clips per step: B = 4 in the inversion, B = 8 under CFG, T = 16,
+    64x64 (M = 262 144 / 524 288 rows at the top level, 16 384 / 32 768 at 16x16, 4 096 / 8 192 at 8x8 — other tile choices than
+    B = 1 / 2 everywhere, and the largest row counts the 32-bit element offsets of the kernels see)."""
+    cfg, ora, ora_dev, ora_h, prod = models
+    x, txt = _inputs(B, 16, 64, 64, seed=112 + B)
+    _check(f'unet_B{B}_T16_64x64', _fwd(prod, x, 521, txt), _fwd(ora_dev, x, 521, txt), _fwd(ora_h, x, 521, txt))
+
+
 def test_forward_56x96(models):
     """(3) 448x768 frames (56x96 latent, 26 of the 30 reference YAMLs): ragged M tiles, N = 5376 keys."""
     cfg, ora, ora_dev, ora_h, prod = models
@@ -315,23 +325,24 @@ def test_sequential_steps_full_width(models, steps):
                             wall_s_fp16_torch_oracle=t_h))
 
 
-def test_two_clips_per_step_match_the_oracle_clip_by_clip(models):
-    """(5c) bench.py's throughput reading denoises TWO clips together (latents [2,4,T,h,w]: UNet batch 2 in the inversion, 4
+def test_clips_denoised_together_match_the_oracle_clip_by_clip(models):
+    """(5c) bench.py's default workload denoises FOUR clips together (latents [4,4,T,h,w]: UNet batch 4 in the inversion, 8
     under CFG — the reference's own batch axis, pipeline_videoswap.py:478-550).  Every clip of the batch must obey the loop
     rule against the oracle run on that clip ALONE: nothing may leak between the clips of a batch (GroupNorm pools per batch
     item, the time-embedding row is shared, text rows are per item), and the larger M picks other kernels."""
     cfg, ora, ora_dev, ora_h, prod = models
     xs, txts, negs = [], [], []
-    for i in range(2):
+    NC = 4
+    for i in range(NC):
         x, txt = _inputs(1, 8, 64, 64, seed=151 + i)
         xs.append(x); txts.append(txt)
         negs.append(torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(17 + i)))
     inv_p, out_p = _product_loops(prod, torch.cat(xs), torch.cat(txts), torch.cat(negs), 3)
-    assert inv_p.shape[0] == 2 and out_p.shape[0] == 2
-    for i in range(2):
+    assert inv_p.shape[0] == NC and out_p.shape[0] == NC
+    for i in range(NC):
         inv_ref, out_ref = _oracle_loops(ora_dev, xs[i], txts[i], negs[i], 3)
         inv_h, out_h = _oracle_loops(ora_h, xs[i], txts[i], negs[i], 3)
-        _check_loops(f'loops_3+3_T8_64x64_clip{i}_of_a_batch_of_2', inv_p[i:i + 1], out_p[i:i + 1], inv_ref, out_ref, inv_h, out_h)
+        _check_loops(f'loops_3+3_T8_64x64_clip{i}_of_a_batch_of_{NC}', inv_p[i:i + 1], out_p[i:i + 1], inv_ref, out_ref, inv_h, out_h)
     assert not torch.equal(out_p[0], out_p[1])
 
 

@@ -72,10 +72,14 @@ for STEP in "$@"; do
       timeout 400 python bench.py --latent-h 56 --latent-w 96 --steps 1 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench448.txt 2>&1; show bench448 1 600 ;;
     bench2)
       timeout 400 python bench.py --clips-per-step 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench2.txt 2>&1; show bench2 1 1500 ;;
+    benchn:*)
+      N=${STEP#benchn:}
+      timeout 600 python bench.py --clips-per-step $N --steps 2 --warmup 1 --no-cpu-baseline --no-extra-reading > $O/${TAG}_benchn$N.txt 2>&1
+      tail -n 1 $O/${TAG}_benchn$N.txt | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['readings']; print('clips/step $N:', d['value'], 'fps; ms_per_step', d['ms_per_step'], 'inv', r['inversion_s_per_clip'], 'smp', r['sampling_s_per_clip'], 'gemm frac', d['roofline']['frac'], 'attainable', d['roofline']['frac_of_attainable'], 'byte-bound share', d['roofline']['byte_bound_time_share'])" ;;
     smoke)
       timeout 400 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/${TAG}_smoke.txt 2>&1; show smoke 3 ;;
     trace)
-      ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -o r05 -- python $R/bench.py --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --prof-samples 0 > $O/${TAG}_prof.log 2>&1 )
+      ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -o r05 -- python $R/bench.py --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --no-extra-reading --prof-samples 0 > $O/${TAG}_prof.log 2>&1 )
       DB=$(find $O/${TAG}_prof -name '*.db' | head -n 1)
       [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $O/${TAG}_kernel_stats.txt 2>&1
       find $O/${TAG}_prof -type f -size +4M -delete 2>/dev/null

@@ -113,7 +113,11 @@ def main(root):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from videoswap_amd.build import source_digest
     with open(os.path.join(root, 'gemm_hbm_traffic.json'), 'w') as f:
+        meta = {}
+        if os.path.exists(os.path.join(root, 'gemm_log.txt.meta.json')):
+            meta = json.load(open(os.path.join(root, 'gemm_log.txt.meta.json')))
         json.dump({'kernel': 'vsx_gemm_f16 (all shapes of one inversion step + one CFG step)', 'launches': n,
+                   'clips_per_step': meta.get('clips_per_step', 1),
                    'lib_digest': source_digest(), 'hbm_bytes_per_launch': tot_hbm / n,
                    'algorithmic_bytes_per_launch': tot_alg / n, 'ratio': tot_hbm / tot_alg,
                    'note': 'FETCH_SIZE x 2 (gfx950 reports half the bytes of wide coalesced reads) + WRITE_SIZE, separate '

@@ -8,7 +8,7 @@ D=$R/gpurun_out/${1:-pmc_shape}
 shift
 mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 1 --warmup 0 --ddim-steps 1 --no-cpu-baseline --prof-samples 0 $*"
+CMD="python $R/bench.py --steps 1 --warmup 0 --ddim-steps 1 --no-cpu-baseline --no-extra-reading --prof-samples 0 $*"
 VSX_GEMM_LOG=$D/gemm_log.txt rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $D/fetch -o p --output-format csv -- $CMD > $D/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $D/write -o p --output-format csv -- $CMD > $D/write.log 2>&1
 rocprofv3 --kernel-trace -d $D/trace -o p --output-format csv -- $CMD > $D/trace.log 2>&1

@@ -7,7 +7,7 @@
 TAG=${1:-pmc_sq}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-CMD="python $R/bench.py --steps 1 --warmup 0 --ddim-steps 1 --no-cpu-baseline --no-graphs --prof-samples 0"
+CMD="python $R/bench.py --steps 1 --warmup 0 --ddim-steps 1 --no-cpu-baseline --no-extra-reading --prof-samples 0"
 mkdir -p $R/gpurun_out/$TAG
 run_pass() {   # name, counters...
   local name=$1; shift
