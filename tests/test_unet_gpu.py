@@ -87,6 +87,31 @@ def test_shared_cfg_prefix_equals_the_duplicated_batch(setup):
         attn1.set_processor(AttnProcessor2_0())
 
 
+def test_shared_cfg_prefix_of_several_clips(setup):
+    """Several clips denoised together (bench.py's default: four per step): `VideoSwapPipeline.__call__` tags its own
+    `torch.cat([latents] * 2)` as two equal halves; the UNet then runs conv_in, the first resnet and the first self-attention on
+    ONE half.  Must match the untagged batch (same arithmetic per element), keep the clips apart, and an untagged batch whose
+    halves merely happen to be equal must not be shared."""
+    blob, ora, prod = setup
+    case = blob['cases']['cfg_adapter_T3_16x24']
+    x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
+    clips = torch.cat([x[:1], x[1:2] * 0.5 + 0.1])                    # two different clips
+    text4 = torch.cat([txt[:1], txt[:1] * 0.7, txt[1:2], txt[1:2] * 0.7])     # [uncond clip 0, 1 ; cond clip 0, 1]
+    plain = torch.cat([clips, clips])
+    tagged = torch.cat([clips, clips])
+    tagged.vsx_cfg_halves_equal = True
+    one_row = torch.zeros(1, 8)
+    assert prod._shared_cfg_prefix(tagged, text4, one_row) == 2 and prod._shared_cfg_prefix(plain, text4, one_row) == 0
+    assert prod._shared_cfg_prefix(tagged, text4[:2], one_row) == 0       # text rows must cover the whole batch
+    with torch.no_grad():
+        a = prod(tagged, 481, text4).sample.float().cpu()
+        b = prod(plain, 481, text4).sample.float().cpu()
+    sync()
+    assert a.shape == b.shape and torch.isfinite(a).all()
+    assert rel_l2(a, b) < 1e-3, rel_l2(a, b)
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a[0], a[2])
+
+
 def test_shared_cfg_prefix_steps_aside_for_a_registered_controller_and_for_two_timesteps(setup):
     """The Prompt-to-Prompt processors are `vsx_native` (they run on the kernels) but NOT shareable: below 32 x 32 latents the
     controller is called on the first self-attention and splits its argument into the two CFG halves (attention_util.py:

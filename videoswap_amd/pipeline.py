@@ -284,8 +284,11 @@ class VideoSwapPipeline:
             # the UNet then knows the halves are identical up to the first cross-attention and computes that prefix once
             if do_cfg and latents.shape[0] == 1:
                 model_input = latents.expand(2, *latents.shape[1:])
+            elif do_cfg:        # several clips denoised together: [uncond clips ; cond clips], tagged as two equal halves
+                model_input = torch.cat([latents] * 2)
+                model_input.vsx_cfg_halves_equal = True
             else:
-                model_input = torch.cat([latents] * 2) if do_cfg else latents
+                model_input = latents
             if adapter_state is not None and n * t2i_start <= i <= n * t2i_end:
                 t2i_residual = list(adapter_state)      # fresh list: the UNet pops from it
             else:

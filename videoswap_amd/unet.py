@@ -663,9 +663,10 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         # stride-0 batch view (`latents.expand(2, ...)`: VideoSwapPipeline does), conv_in, the first resnet and the first
         # self-attention (N = H*W keys: the largest attention launch of the model) run once for both halves.
         shared_geo = None
-        if self._shared_cfg_prefix(sample, encoder_hidden_states, silu_emb):
-            shared_geo = Geometry(1, F)
-            x = ops.pack_latents(sample[:1].contiguous(), 8)
+        half = self._shared_cfg_prefix(sample, encoder_hidden_states, silu_emb)
+        if half:
+            shared_geo = Geometry(half, F)
+            x = ops.pack_latents(sample[:half].contiguous(), 8)
         else:
             x = ops.pack_latents(sample.contiguous(), 8)        # [B*F, H, W, 8] (latent channels zero-padded)
         x = self.conv_in(x)
@@ -732,23 +733,27 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         return super()._apply(fn, *args, **kwargs)
 
     def _shared_cfg_prefix(self, sample, text, silu_emb):
-        """Can the two batch items share everything in front of the first cross-attention?  Only when the caller PROVES
-        that they are identical (a stride-0 batch dimension) AND share the timestep (one time-embedding row: a [2] timestep
-        tensor gives two rows, and the shared prefix would hand item 0's row to both), the first block is a cross-attention
-        block whose first self- and cross-attention run on this package's plain fused processors (a Prompt-to-Prompt
-        controller hooked there is `vsx_native` too, but it expects both halves of the batch: below 32 x 32 latents it is
-        called on that very layer), and the clip is not frame-sharded."""
-        if sample.shape[0] != 2 or sample.stride(0) != 0 or self._frame_shard is not None:
-            return False
+        """Can the two CFG halves of the batch share everything in front of the first cross-attention?  -> the number of batch
+        items of ONE half (0: no).  Only when the caller PROVES that the halves are identical — a stride-0 batch dimension
+        (`latents.expand(2, ...)`: one clip), or, for several clips denoised together, the tag `vsx_cfg_halves_equal` that
+        `VideoSwapPipeline.__call__` puts on its own `torch.cat([latents] * 2)` — AND they share the timestep (one time-
+        embedding row: a [B] timestep tensor gives B rows, and the shared prefix would hand the first half's rows to both), the
+        first block is a cross-attention block whose first self- and cross-attention run on this package's plain fused
+        processors (a Prompt-to-Prompt controller hooked there is `vsx_native` too, but it expects both halves of the batch:
+        below 32 x 32 latents it is called on that very layer), and the clip is not frame-sharded."""
+        nb = sample.shape[0]
+        proven = (nb == 2 and sample.stride(0) == 0) or (nb % 2 == 0 and getattr(sample, 'vsx_cfg_halves_equal', False))
+        if not proven or self._frame_shard is not None:
+            return 0
         if silu_emb.shape[0] != 1:
-            return False
-        if text is None or text.shape[0] != 2 or os.environ.get('VSX_CFG_SHARED_PREFIX', '1') == '0':
-            return False
+            return 0
+        if text is None or text.shape[0] != nb or os.environ.get('VSX_CFG_SHARED_PREFIX', '1') == '0':
+            return 0
         blk = self.down_blocks[0]
         if not getattr(blk, 'has_cross_attention', False) or len(blk.attentions) == 0:
-            return False
+            return 0
         tb = blk.attentions[0].transformer_blocks[0]
-        return _shareable(tb.attn1) and _shareable(tb.attn2)
+        return nb // 2 if (_shareable(tb.attn1) and _shareable(tb.attn2)) else 0
 
     def _graphable(self, sample, silu_emb, text):
         if self._frame_shard is not None or not sample.is_cuda or silu_emb.shape[0] != 1:
