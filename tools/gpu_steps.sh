@@ -72,6 +72,10 @@ for STEP in "$@"; do
       timeout 400 python bench.py --latent-h 56 --latent-w 96 --steps 1 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench448.txt 2>&1; show bench448 1 600 ;;
     bench2)
       timeout 400 python bench.py --clips-per-step 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench2.txt 2>&1; show bench2 1 1500 ;;
+    benchenv:*)       # benchenv:NAME=VALUE:clips — one quick bench line under an environment switch (in-situ A/B of an option)
+      A=${STEP#benchenv:}; E=${A%%:*}; N=${A##*:}
+      env $E timeout 600 python bench.py --clips-per-step $N --steps 2 --warmup 1 --no-cpu-baseline --no-extra-reading > $O/${TAG}_benchenv.txt 2>&1
+      tail -n 1 $O/${TAG}_benchenv.txt | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['readings']; print('$E clips/step $N:', d['value'], 'fps; inv', r['inversion_s_per_clip'], 'smp', r['sampling_s_per_clip'])" ;;
     benchn:*)
       N=${STEP#benchn:}
       timeout 600 python bench.py --clips-per-step $N --steps 2 --warmup 1 --no-cpu-baseline --no-extra-reading > $O/${TAG}_benchn$N.txt 2>&1
