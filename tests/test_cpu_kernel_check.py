@@ -62,6 +62,7 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
             ('22', '0,16,32'),                   # image rows of 32 pixels: ONE A slab per filter row read at three row offsets
                                                  # (default) = a private slab per tap (16), bit for bit; 32 = every CU walks the
                                                  # pieces of a slab in the same order
+            ('18', '0,16'),                      # image rows of 16 pixels (round 5): left / right padding lanes INSIDE a 32-row block
             ('34', '0')]                         # sub-pixel form of the nearest-2x convolution: four classes of output pixels
     if os.environ.get('VSX_CPU_CHECK_FULL'):     # a minute or more each: two sources, image rows as long as the tile, W = 24
         runs += [('23', '0,16,32'), ('31', '0,16'), ('33', '0,8'), ('35', '0')]
@@ -72,7 +73,7 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     # ordering hazards: the multi-tile, multi-slab case again with every DMA piece landing as LATE as the kernel's own
     # waits allow (the default run above lands them at issue, the other extreme); see tools/cpu_check/hip_gemm.h
-    for case, scheds in (('1', '0,8'), ('22', '0')):      # ('22': the shared A slab's own ring parity)
+    for case, scheds in (('1', '0,8'), ('22', '0'), ('15', '0')):      # ('22': the shared A slab's own ring parity; '15': image rows of 8 pixels)
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, CPUHIP_DMA='late'))
         print(r.stdout)

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     int t_kh = 0, t_kw = 0, t_c = 0;             // conv: filter tap / channel base of the next slab
     bool t_second = false, t_dirty = true, t_src_dirty = true;
     const bool tap_inner = CONV >= 2 || (CONV && (flags & PP_CONV_TAP_MAJOR) == 0);
-    // SHARED A SLAB (stride-1 3x3, W a power of two in [32, BM]; launch_pp decides).  The windows of the taps (kh, 0..2) are
+    // SHARED A SLAB (stride-1 3x3, W a power of two in [8, BM]; launch_pp decides).  The windows of the taps (kh, 0..2) are
     // one-pixel shifts of each other, and a tile starts at the first pixel of an image row: the A slab of tap (kh, 1) is
     // streamed ONCE per (channel slab, kh) and the MFMAs of kw = 0 / 2 read their fragments one LDS row lower / higher; the
     // lanes whose pixel sits at the left / right image edge read a zero row instead.  A slab (32 KiB of 72) then arrives with
@@ -683,8 +683,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
 #pragma unroll
         for (int i = 0; i < (ashift ? TM : 1); ++i) {
             const int row0 = wr * WM + i * 32;                   // tile row of the block's first row (a tile starts at w = 0)
-            const bool edge = (c_kw == 0 && l31 == 0 && (row0 & wmask) == 0) ||
-                              (c_kw == 2 && l31 == 31 && ((row0 + 32) & wmask) == 0);
+            // image column of this lane's pixel (a tile starts at w = 0 and W divides the tile height): the left neighbour of
+            // column 0 and the right neighbour of column W - 1 are padding.  (Image rows of 8 / 16 pixels — the 8 x 8 / 16 x 16
+            // levels, on this kernel since several clips are denoised together — have such lanes inside a 32-row block, not
+            // only at its ends.)
+            const int col = (row0 + l31) & wmask;
+            const bool edge = (c_kw == 0 && col == 0) || (c_kw == 2 && col == wmask);
             aoff[i] = edge ? ZERO_OFF : base + i * 4096;
         }
     };
@@ -887,9 +891,9 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     p.pp_flags = (int)(gemm_option("pp_sched") & (PP_TILES_LINEAR | PP_CONV_TAP_MAJOR | PP_CONV_PRIVATE_A | PP_COMMON_ORDER));
     int conv = p.a_mode == 1 ? 1 : 0;
     // shared A slab (gemm_pp_kernel: "SHARED A SLAB"): stride-1 3x3 convolutions in the taps-inner order whose image rows
-    // are a power of two of at least one 32-row MFMA block and at most one tile, so that every tile starts at w = 0
+    // are a power of two of at least 8 pixels and at most one tile, so that every tile starts at w = 0
     if (conv && (p.pp_flags & (PP_CONV_TAP_MAJOR | PP_CONV_PRIVATE_A)) == 0 && p.ks == 3 && p.stride == 1 && p.ups == 0 &&
-        p.pad == 1 && p.Wo == p.W && p.Ho == p.H && p.W >= 32 && p.W <= bm && (p.W & (p.W - 1)) == 0)
+        p.pad == 1 && p.Wo == p.W && p.Ho == p.H && p.W >= 8 && p.W <= bm && (p.W & (p.W - 1)) == 0)
         p.pp_flags |= PP_CONV_ASHIFT_ON, conv = 2;
     if (conv && p.sp_Mc > 0) conv = 3;
     const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0) |
