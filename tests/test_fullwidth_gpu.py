@@ -169,14 +169,27 @@ def test_forward_benchmark_shape(models):
            _fwd(ora_h, x1, -19, txt1))
 
 
-@pytest.mark.parametrize('B', [4, 8])
-def test_forward_clip_batch_shapes(models, B):
+def test_forward_clip_batch_shapes(models):
     """(2b) the UNet batches of bench.py's default workload, four clips per step: B = 4 in the inversion, B = 8 under CFG, T = 16,
     64x64 (M = 262 144 / 524 288 rows at the top level, 16 384 / 32 768 at 16x16, 4 096 / 8 192 at 8x8 — other tile choices than
-    B = 1 / 2 everywhere, and the largest row counts the 32-bit element offsets of the kernels see)."""
+    B = 1 / 2 everywhere, and the largest row counts the 32-bit element offsets of the kernels see).  B = 4 goes against the
+    oracle like every other shape; B = 8 (three minutes of fp32 oracle on the device) is pinned to it instead: batch items are
+    independent, so the B = 8 output must equal the two B = 4 outputs of its halves up to what another kernel choice may
+    change (the same fp16 roundings almost everywhere: a few 1e-4), and each half obeys the oracle rule through the B = 4 case."""
     cfg, ora, ora_dev, ora_h, prod = models
-    x, txt = _inputs(B, 16, 64, 64, seed=112 + B)
-    _check(f'unet_B{B}_T16_64x64', _fwd(prod, x, 521, txt), _fwd(ora_dev, x, 521, txt), _fwd(ora_h, x, 521, txt))
+    x, txt = _inputs(8, 16, 64, 64, seed=120)
+    out8 = _fwd(prod, x, 521, txt)
+    assert torch.isfinite(out8).all()
+    ref4 = _fwd(ora_dev, x[:4], 521, txt[:4])
+    out4 = _fwd(prod, x[:4], 521, txt[:4])
+    _check('unet_B4_T16_64x64', out4, ref4, _fwd(ora_h, x[:4], 521, txt[:4]))
+    out4b = _fwd(prod, x[4:], 521, txt[4:])
+    e_a, e_b = rel_l2(out8[:4], out4), rel_l2(out8[4:], out4b)
+    e8 = rel_l2(out8[:4], ref4)
+    _record('unet_B8_T16_64x64', first_half_vs_B4_launch=e_a, second_half_vs_B4_launch=e_b, first_half_rel_l2_vs_fp32_oracle=e8)
+    assert e_a <= 1e-3 and e_b <= 1e-3, (e_a, e_b)
+    assert e8 <= CAP_FORWARD
+    assert not torch.equal(out8[0], out8[4])
 
 
 def test_forward_56x96(models):

@@ -130,12 +130,13 @@ def main():
     print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
     print(f'{"shape":44s} {"n":>3s} ' + ' '.join(f'{v[0]:>9s}' for v in variants) + '   best TF/s  speedup  fwd-ms tile -> best')
     tot_old = tot_best = 0.0
+    level_of = {16 * args.batch * hw * hw: hw for hw in (64, 32, 16, 8)}     # rows of a plain GEMM -> latent side of its level
     for kind, name, a, count in shapes(args.batch):
         if args.kinds and kind not in args.kinds.split(','):
             continue
         if args.levels:
-            lvl = a['hw'] if kind == 'conv' else {131072: 64, 32768: 32, 8192: 16, 65536: 64, 16384: 32, 4096: 16}.get(a['M'], 0)
-            if str(lvl) not in args.levels.split(','):
+            lvl = a['hw'] if kind == 'conv' else level_of[a['M']]
+            if str(lvl) not in args.levels.replace('+', ',').split(','):
                 continue
         torch.manual_seed(0)
         fn, flop = make(kind, a)
