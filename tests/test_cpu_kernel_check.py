@@ -63,7 +63,8 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
                                                  # (default) = a private slab per tap (16), bit for bit; 32 = every CU walks the
                                                  # pieces of a slab in the same order
             ('18', '0,16'),                      # image rows of 16 pixels (round 5): left / right padding lanes INSIDE a 32-row block
-            ('34', '0')]                         # sub-pixel form of the nearest-2x convolution: four classes of output pixels
+            ('34', '0'),                         # sub-pixel form of the nearest-2x convolution: four classes of output pixels
+            ('100', '0,8'), ('101', '0')]        # transposed store (V^T) of the persistent kernel, plain and with the LayerNorm identity
     if os.environ.get('VSX_CPU_CHECK_FULL'):     # a minute or more each: two sources, image rows as long as the tile, W = 24
         runs += [('23', '0,16,32'), ('31', '0,16'), ('33', '0,8'), ('35', '0')]
     # (`make -C tools/cpu_check run` walks every case: the remaining kernel kinds, stride 2, nearest-2x, K tails)
@@ -104,7 +105,8 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
     # round 5: the XCD block grid of the tile kernels (21: bit for bit like the linear walk, and actually chosen) and the residual
     # prefetch behind the last slab with its exact vmcnt counts (22) — the latter also with every DMA piece landing as late as
     # the kernel's own counted waits allow (an under-counted wait multiplies a slab that has not landed: the run fails)
-    for case, late in (('21', False), ('22', False), ('22', True), ('0', True), ('16', True)):
+    # 23: the persistent kernel's transposed store through the entry point, bit for bit like the tile kernels' (gemm_pp = 4)
+    for case, late in (('21', False), ('22', False), ('22', True), ('0', True), ('16', True), ('23', False)):
         r = subprocess.run([exe, case], capture_output=True, text=True, timeout=900,
                            env=dict(env, CPUHIP_DMA='late') if late else env)
         print('late DMA' if late else '', r.stdout)

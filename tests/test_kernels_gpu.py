@@ -229,6 +229,24 @@ def test_persistent_linear(M, N, K, res, sched):
         assert torch.equal(old, new), 'persistent and tile kernels must agree bit for bit'
 
 
+@pytest.mark.parametrize('ln', [False, True])
+@pytest.mark.parametrize('rows,nimg,N,K', [(4096, 16, 320, 320), (1024, 64, 640, 640), (256, 256, 1280, 1280), (4096, 128, 320, 320)])
+def test_persistent_transposed_store(rows, nimg, N, K, ln):
+    """The V^T projections of the 64x64 / 32x32 / 16x16 levels on the persistent kernel (round 5: epilogue_vt, full 128-byte lines of
+    V^T per wave instead of 8-byte scatters): bit for bit like the tile kernels' transposed store, plain and with the folded LayerNorm
+    (what the self-attentions of the model launch); 128 images x 4096 rows = the UNet batch 8 of four clips per step."""
+    o = ops()
+    x, gamma, beta = _ln_inputs(nimg * rows, K, seed=150)
+    w, b = rnd(N, K, seed=151, scale=K ** -0.5), rnd(N, seed=152)
+    o.set_option('pp_sched', 0)
+    src = (lambda: o.DeferredLN(x, gamma, beta, 1e-5)) if ln else (lambda: x)
+    old, new = both_gemm_paths(lambda: o.linear_vt(src(), w, b, rows))
+    xin = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5) if ln else x.float()
+    ref = (xin @ w.float().t() + b.float()).view(nimg, rows, N).transpose(1, 2)
+    assert rel_err(new[:, :, :rows], ref) < 2e-3
+    assert torch.equal(old, new), 'persistent and tile kernels must agree bit for bit'
+
+
 @pytest.mark.parametrize('M,N,K', [(65536, 1280, 320), (32768, 2560, 640), (8192, 5120, 1280), (20000, 160, 320)])
 def test_persistent_geglu(M, N, K):
     x, w, b = rnd(M, K, seed=94), rnd(2 * N, K, seed=95, scale=K ** -0.5), rnd(2 * N, seed=96)

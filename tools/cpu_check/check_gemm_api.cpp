@@ -388,6 +388,23 @@ int main(int argc, char** argv) {
         vsx_set_option("tile_tune", 0);
         vsx_set_option("pp_sched", 0);
     }
+    if (only < 0 || only == nplain + 10) {
+        // the persistent kernel's transposed store (gemm_pp.hip, epilogue_vt) through the entry point: bit for bit like the tile
+        // kernels' V^T store, plain and with the LayerNorm identity (gemm_pp = 4: 256-row tiles however few)
+        for (int ln = 0; ln < 2; ++ln) {
+            Plain c = {ln ? "V^T store 512x320x128 + LayerNorm fold, persistent vs tile kernels" : "V^T store 512x320x128, persistent vs tile kernels",
+                       512, 320, 128, false, false, false, ln != 0, true, 0, 256, 0, false};
+            rng_state = 555u;
+            const auto a = run_plain(c, false);
+            c.pp = 4;
+            rng_state = 555u;
+            const auto b = run_plain(c, true);
+            const bool same = memcmp(a.data(), b.data(), a.size() * sizeof(half_t)) == 0;
+            printf("%-58s %s\n", "  ... bit-identical to gemm_pp = 0", same ? "ok" : "FAIL");
+            n_bad += same ? 0 : 1;
+        }
+        vsx_set_option("gemm_pp", 1);
+    }
     printf(n_bad ? "%d check(s) FAILED\n" : "all checks passed\n", n_bad);
     return n_bad ? 1 : 0;
 }

@@ -43,7 +43,7 @@ static std::vector<half_t> randh(size_t n, float scale = 1.0f) {
 }
 static double gelu(double x) { return 0.5 * x * (1.0 + erf(x / sqrt(2.0))); }
 
-struct Case { const char* name; long M, N, K; bool res, geglu; int bm; bool ln = false; };
+struct Case { const char* name; long M, N, K; bool res, geglu; int bm; bool ln = false; long vt = 0; };     // vt: rows per image of the transposed store (c_mode 1), 0 = row-major C
 
 static int n_bad = 0;
 static std::vector<long> g_scheds = {0, 8, 4, 12, 16, 32};      // pp_sched bits: 8 = linear tile walk instead of the 2-D one; 4 = conv K order tap-major (default: taps of a channel slab back to back); 16 = a private A slab per tap (default where the shape allows: one A slab per filter row, read at three row offsets); 32 = every CU issues the pieces of a slab in the same order (default: from a per-CU starting point)
@@ -87,7 +87,8 @@ static void run_case(const Case& c) {
             };
             double v = c.geglu ? dot(n) * gelu(dot(c.N + n)) : dot(n);
             if (c.res) v += (double)R[m * c.N + n];
-            want[m * c.N + n] = v;
+            // transposed store: V^T[img][n][row in image], image stride N * rows_per_img (ldvt = rows_per_img here)
+            want[c.vt ? ((m / c.vt) * c.N + n) * c.vt + m % c.vt : m * c.N + n] = v;
         }
     std::vector<half_t> first;
     for (long sched : g_scheds) {
@@ -104,6 +105,7 @@ static void run_case(const Case& c) {
         p.a_bytes = (unsigned)(((c.M - 1) * c.K + c.K) * 2);
         p.b_bytes = (unsigned)(((brows - 1) * c.K + c.K) * 2);
         p.splitk = 1;
+        if (c.vt) { p.c_mode = 1; p.ldc = c.vt; p.c_rows_per_img = c.vt; p.c_img_stride = c.N * c.vt; p.c_pack4 = 1; }
         if (!pp_supported(p)) { printf("%s: not eligible\n", c.name); return; }
         // row statistics of the output (EPI_STATS: plain / addend epilogues only): 6 parts per 320 columns
         const bool stats = pp_rowstats_ok(p);
@@ -302,6 +304,12 @@ int main(int argc, char** argv) {
         {"rowscale 300x320x64 128-row", 300, 320, 64, false, false, 128, true},
         {"rowscale geglu 512x160x64", 512, 160, 64, false, true, 256, true},
     };
+    // transposed store of the persistent kernel (round 5; cases 100, 101 so that the numbering above stays): V^T[img][n][row],
+    // 256 / 512 rows per image, plain and with the LayerNorm identity, several tiles per workgroup
+    const Case vt_cases[] = {
+        {"V^T 512x320x128, 256 rows per image", 512, 320, 128, false, false, 256, false, 256},
+        {"V^T rowscale 1024x640x64, 512 rows per image", 1024, 640, 64, false, false, 256, true, 512},
+    };
     // usage: check_gemm_pp [case index | -1 = all] [comma-separated schedules]
     cpuhip_num_cus = 24;                  // three workgroups per emulated XCD: blockIdx.x >> 3 takes the values 0, 1, 2
     const int only = argc > 1 ? atoi(argv[1]) : -1;
@@ -312,6 +320,8 @@ int main(int argc, char** argv) {
     const int ncases = (int)(sizeof(cases) / sizeof(cases[0]));
     for (int i = 0; i < ncases; ++i)
         if (only < 0 || only == i) run_case(cases[i]);
+    for (int i = 0; i < 2; ++i)
+        if (only < 0 || only == 100 + i) run_case(vt_cases[i]);
     if (only < 0 || only == ncases) run_conv("conv3x3 2x8x8 64+64->320", 2, 8, 8, 64, 64, 320, 1, 0, 256);
     if (only < 0 || only == ncases + 1) run_conv("conv3x3 3x16x8 128->320 /s2 128-row", 3, 16, 8, 128, 0, 320, 2, 0, 128);    // 32 rows per vector
     if (only < 0 || only == ncases + 2) run_conv("conv3x3 2x8x8 64->320 nearest-2x", 2, 8, 8, 64, 0, 320, 1, 1, 128);

@@ -38,6 +38,8 @@ def shapes(B):
             out.append(('plain', f'qk {c}->{2 * c}', dict(M=M, N=2 * c, K=c, res=False), n_blk))
             out.append(('geglu', f'geglu {c}->{4 * c}', dict(M=M, N=4 * c, K=c), 2 * n_blk))
             out.append(('plain', f'ff2 {4 * c}->{c} +res', dict(M=M, N=c, K=4 * c, res=True), 2 * n_blk))
+            # V^T projection of the spatial self-attention (transposed store, LayerNorm folded in): one per transformer block
+            out.append(('vt', f'v^T {c}->{c} (+LN)', dict(M=M, N=c, K=c, rows=hw * hw), n_blk))
     convs = [(64, 320, 0, 320, 1, False, 7), (64, 320, 320, 320, 1, False, 2), (64, 640, 320, 320, 1, False, 1),
              (64, 320, 0, 320, 2, False, 1), (32, 640, 0, 640, 1, False, 6), (32, 640, 640, 640, 1, False, 1),
              (32, 320, 0, 640, 1, False, 1), (32, 1280, 640, 640, 1, False, 1), (32, 640, 0, 640, 1, True, 1),
@@ -61,6 +63,11 @@ def make(kind, a, packed=False):
     """-> (launch closure, algorithmic FLOP); packed: the closure passes the piece-major weight (development library,
     pp_sched + 16)"""
     pk = pack_b if packed else (lambda t: t)
+    if kind == 'vt':
+        M, N, K = a['M'], a['N'], a['K']
+        x, w = r(M, K), pk(r(N, K, scale=K ** -0.5))
+        gamma, beta = r(K), r(K)
+        return (lambda: ops.linear_vt(ops.DeferredLN(x, gamma, beta, 1e-5), w, None, a['rows'])), 2.0 * M * N * K
     if kind in ('plain', 'geglu'):
         M, N, K = a['M'], a['N'], a['K']
         x = r(M, K)

@@ -1261,13 +1261,14 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
     const int pp = pp_mode();
     const bool pp_ok = pp != 0 && wide && nbatch == 1 && (splits <= 1 || pp >= 2) && !force_tile() && pp_supported(p);
     // option gemm_pp: 0 never, 1 automatic (thresholds from tools/gemm_ab.py: profiles/r03_gemm_ab_b{1,2}.txt), 2 = 256-row
-    // tiles wherever >= 64 of them exist (else 128-row), 3 = 128-row tiles wherever >= 32 exist.
+    // tiles wherever >= 64 of them exist (else 128-row), 3 = 128-row tiles wherever >= 32 exist, 4 = 256-row tiles for every
+    // eligible problem however small (tests: tools/cpu_check).
     // Automatic: 256-row tiles from 192 of them (0.75 per CU: qkv 1280->3840 at B = 1, 47 instead of 60 us); 128-row
     // tiles for the plain GEMMs with about ONE such tile per CU (the 640 / 1280-wide projections at M = 16 384 / 8 192 and
     // ff2 at those sizes: 7-10 % over the tile kernels; the convolutions of that size stay on the tile kernels)
     const long t128 = blocks(128, 320);
-    const bool pp256 = pp_ok && pp != 3 && (blocks(256, 320) >= 192 || (pp == 2 && blocks(256, 320) >= 64));
-    const bool pp128 = !pp256 && pp_ok && ((pp >= 2 && t128 >= 32) || (pp == 1 && p.a_mode != 1 && t128 >= 240 && t128 <= 272));
+    const bool pp256 = pp_ok && pp != 3 && (blocks(256, 320) >= 192 || (pp == 2 && blocks(256, 320) >= 64) || pp == 4);
+    const bool pp128 = !pp256 && pp_ok && p.c_mode != 1 && ((pp >= 2 && t128 >= 32) || (pp == 1 && p.a_mode != 1 && t128 >= 240 && t128 <= 272));
     // row statistics of the output (vsx.h, ABI 8): only the persistent kernel's staged row passes produce them
     const long stat_parts = (pp256 || pp128) && pp_rowstats_ok(p) ? (cols / 320) * 6 : 0;
     if (dry) {

@@ -228,6 +228,75 @@ constexpr int EPI_ADD = 1;          // + residual, or + row vector (one of the t
 constexpr int EPI_LN = 2;           // LayerNorm folded into the GEMM (rowscale / colvec)
 constexpr int EPI_GEGLU = 4;        // h * gelu(g)
 constexpr int EPI_STATS = 8;        // row statistics of the output for a LayerNorm that follows (not with LN / GEGLU)
+constexpr int EPI_VT = 16;          // transposed store (c_mode 1: V^T for the attention kernels); bias / folded LayerNorm only, 256-row tiles
+
+// Transposed epilogue of one wave (TM = 2, round 5).  C^T[n][row in image] is what the attention kernels read (vsx.h, c_mode 1); a wave's
+// 64 rows are exactly ONE 128-byte line of every V^T row n of its 160 columns, and a 256-row tile lies inside one image (the host
+// checks rows_per_img % 256 == 0).  Writing that from the accumulator layout costs 32 different V^T rows x 8 bytes per store
+// instruction — the workgroup-per-tile kernels do, and run the V^T projections at 0.27 - 0.47 PF/s where the same GEMM with a
+// row-major C reaches 0.46 - 0.73.  Here a chunk of 32 columns goes through the wave's staging area TRANSPOSED ([n][m], fp32) and is
+// read back with a lane owning 8 consecutive m of one n: 8 lanes store one full line.  Pitch 68 floats and a lane -> (n, octet)
+// assignment that follows the hardware's 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32): every
+// group reads two n rows of opposite parity, 8 octets each, i.e. all 64 banks once.  Same fp32 operation order as the tile kernels'
+// transposed store (scale, LayerNorm identity, bias): bit-identical results.
+template <bool LN>
+__device__ __forceinline__ void epilogue_vt(f16v (&acc)[5][2], float* stg, const int mrow0, const int ncol0, const int lane) {
+    kparams_t p = kernarg_params();
+    constexpr int PITCH = 68;
+    static_assert(32 * PITCH * 4 <= EP_BYTES, "the transposed chunk fits the wave's staging area");
+    const int l31 = lane & 31, hi = lane >> 5;
+    const float alpha = p->alpha;
+    // read-back coordinates of this lane: position inside its 16-lane ds_read_b128 group -> (n row of the pass, octet of m)
+    const bool in_a = l31 < 4 || (l31 >= 12 && l31 < 16) || (l31 >= 20 && l31 < 28);
+    const int pos = in_a ? (l31 < 4 ? l31 : (l31 < 16 ? l31 - 8 : l31 - 12)) : (l31 < 12 ? l31 - 4 : (l31 < 20 ? l31 - 8 : l31 - 16));
+    const int nl = 2 * (2 * hi + (in_a ? 0 : 1)) + (pos >> 3);       // 0 .. 7
+    const int m8 = (pos & 7) * 8;
+    float rs[LN ? 8 : 1], rt[LN ? 8 : 1];
+    if constexpr (LN) {
+        const float* rsp = p->rowscale + 2 * (size_t)(unsigned)(mrow0 + m8);       // (rstd, -rstd * mean) of this lane's 8 rows
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4v v = *reinterpret_cast<const f4v*>(rsp + 4 * q);
+            rs[2 * q] = v[0]; rt[2 * q] = v[1]; rs[2 * q + 1] = v[2]; rt[2 * q + 1] = v[3];
+        }
+    }
+    const half_t* bias = p->bias;
+    const float* cvp = p->colvec;
+    const unsigned rpi = (unsigned)p->c_rows_per_img;
+    const unsigned img = (unsigned)mrow0 / rpi;                         // wave-uniform: the tile lies inside one image
+    half_t* base = p->C + (long)img * p->c_img_stride + ((unsigned)mrow0 - img * rpi) + m8;
+    const long ldc = p->ldc;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    stg[(8 * g + 4 * hi + e) * PITCH + i * 32 + l31] = acc[j][i][4 * g + e] * alpha;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int nloc = pass * 8 + nl;
+            const int n = ncol0 + j * 32 + nloc;
+            const f4v a = *reinterpret_cast<const f4v*>(stg + nloc * PITCH + m8);
+            const f4v b = *reinterpret_cast<const f4v*>(stg + nloc * PITCH + m8 + 4);
+            float o[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            if constexpr (LN) {
+                const float cvn = cvp[n];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = __builtin_fmaf(rs[e], o[e], rt[e] * cvn);
+            }
+            const float bv = bias ? (float)bias[n] : 0.f;
+            h8 pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk[e] = (half_t)(o[e] + bv);
+            *reinterpret_cast<h8*>(base + (long)n * ldc) = pk;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 template <int TM, int EPI, int PD, bool SUBPIX = false>
 __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, const int mrow0, const int ncol0,
@@ -235,6 +304,11 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
     constexpr bool ADD = (EPI & EPI_ADD) != 0, LN = (EPI & EPI_LN) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
     constexpr bool STATS = (EPI & EPI_STATS) != 0;
     static_assert(!STATS || (!LN && !GEGLU), "row statistics come from the plain / addend epilogues");
+    if constexpr ((EPI & EPI_VT) != 0) {
+        static_assert(TM == 2 && !ADD && !GEGLU && !STATS && !SUBPIX, "the transposed store: 256-row tiles, bias / folded LayerNorm only");
+        epilogue_vt<LN>(acc, stg, mrow0, ncol0, lane);
+        return;
+    }
     kparams_t p = kernarg_params();
     // statistics part of this wave's first chunk: 6 parts per 320 columns = (column half wc) x (chunks of 64, 64, 32 columns)
     const int part0 = STATS ? (ncol0 / 160) * 3 : 0;
@@ -868,7 +942,15 @@ bool pp_rowstats_ok(const GemmParams& p) {
 bool pp_supported(const GemmParams& p) {
     // no column edge (N a multiple of the tile), 16-byte epilogue accesses, fast-tap convolutions, 32-bit offsets
     const long cols = p.geglu ? 2 * p.N : p.N;
-    if (cols % 320 != 0 || p.c_mode != 0 || p.splitk > 1) return false;
+    if (cols % 320 != 0 || p.splitk > 1) return false;
+    if (p.c_mode == 1) {
+        // transposed store (epilogue_vt): a 256-row tile inside one image, one full 128-byte line of every V^T row per wave
+        if (p.a_mode != 0 || p.geglu || p.residual || p.rowvec || p.rowstats || p.c_rows_per_img % 256 != 0 || p.M % 256 != 0 ||
+            p.ldc % 8 != 0 || p.c_img_stride % 8 != 0 || !vsx_aligned16(p.C) || !vsx_aligned16(p.rowscale))
+            return false;
+    } else if (p.c_mode != 0) {
+        return false;
+    }
     if (!p.vec8 || (p.residual && !p.rvec8)) return false;
     if (!vsx_aligned16(p.bias) || !vsx_aligned16(p.rowvec) || !vsx_aligned16(p.colvec)) return false;      // 16-byte epilogue loads
     // one prefetched addend: residual or row vector (not both; not under GEGLU); a 32-row block meets <= 2 row vectors
@@ -897,7 +979,8 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
         p.pp_flags |= PP_CONV_ASHIFT_ON, conv = 2;
     if (conv && p.sp_Mc > 0) conv = 3;
     const int epi = (p.geglu ? EPI_GEGLU : 0) | (p.rowscale ? EPI_LN : 0) | (p.residual || p.rowvec ? EPI_ADD : 0) |
-                    (p.rowstats ? EPI_STATS : 0);
+                    (p.rowstats ? EPI_STATS : 0) | (p.c_mode == 1 ? EPI_VT : 0);
+    if (p.c_mode == 1 && bm != 256) return vsx_fail(VSX_E_UNSUPPORTED, "gemm_pp: the transposed store runs on 256-row tiles");
 #define VSX_PP_CASE(TM_, CONV_, EPI_) \
     if ((bm == 256) == (TM_ == 2) && conv == CONV_ && epi == (EPI_)) return launch_one<TM_, CONV_, (EPI_)>(p, stream);
 #define VSX_PP_CASES(TM_)                             \
@@ -915,6 +998,8 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     VSX_PP_CASE(TM_, 0, EPI_STATS)                \
     VSX_PP_CASE(TM_, 0, EPI_STATS | EPI_ADD)
     VSX_PP_CASES(2)
+    VSX_PP_CASE(2, 0, EPI_VT)
+    VSX_PP_CASE(2, 0, EPI_VT | EPI_LN)
     VSX_PP_CASES(1)
 #undef VSX_PP_CASES
 #undef VSX_PP_CASE
