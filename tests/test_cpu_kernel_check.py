@@ -64,7 +64,7 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
                                                  # pieces of a slab in the same order
             ('18', '0,16'),                      # image rows of 16 pixels (round 5): left / right padding lanes INSIDE a 32-row block
             ('34', '0'),                         # sub-pixel form of the nearest-2x convolution: four classes of output pixels
-            ('100', '0,8'), ('101', '0')]        # transposed store (V^T) of the persistent kernel, plain and with the LayerNorm identity
+            ('100', '0'), ('101', '0')]        # transposed store (V^T) of the persistent kernel, plain and with the LayerNorm identity
     if os.environ.get('VSX_CPU_CHECK_FULL'):     # a minute or more each: two sources, image rows as long as the tile, W = 24
         runs += [('23', '0,16,32'), ('31', '0,16'), ('33', '0,8'), ('35', '0')]
     # (`make -C tools/cpu_check run` walks every case: the remaining kernel kinds, stride 2, nearest-2x, K tails)
@@ -74,7 +74,7 @@ def test_persistent_gemm_schedules_run_from_source_on_the_cpu(tmp_path):
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     # ordering hazards: the multi-tile, multi-slab case again with every DMA piece landing as LATE as the kernel's own
     # waits allow (the default run above lands them at issue, the other extreme); see tools/cpu_check/hip_gemm.h
-    for case, scheds in (('1', '0,8'), ('22', '0'), ('15', '0')):      # ('22': the shared A slab's own ring parity; '15': image rows of 8 pixels)
+    for case, scheds in (('1', '0'), ('22', '0'), ('15', '0')):      # ('22': the shared A slab's own ring parity; '15': image rows of 8 pixels)
         r = subprocess.run([exe, case, scheds], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, CPUHIP_DMA='late'))
         print(r.stdout)
@@ -96,6 +96,7 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     env = {k: v for k, v in os.environ.items() if k not in ('VSX_TUNE_TILE', 'VSX_GEMM_PP', 'VSX_PP_SCHED')}
+    env['CPUHIP_QUICK'] = '1'          # cases 21 / 22: a subset of their sub-cases (`make -C tools/cpu_check run` walks all)
     # (13: the persistent kernel, covered above; 20: the nearest-2x convolution in its sub-pixel form against the nine-tap
     # convolution of the upsampled image, and the refusal where the persistent kernel would not run)
     for case in [str(c) for c in range(13)] + ['14', '15', '16', '17', '18', '20']:
@@ -106,13 +107,13 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
     # prefetch behind the last slab with its exact vmcnt counts (22) — the latter also with every DMA piece landing as late as
     # the kernel's own counted waits allow (an under-counted wait multiplies a slab that has not landed: the run fails)
     # 23: the persistent kernel's transposed store through the entry point, bit for bit like the tile kernels' (gemm_pp = 4)
-    for case, late in (('21', False), ('22', False), ('22', True), ('0', True), ('16', True), ('23', False)):
+    for case, late in (('21', False), ('22', True), ('23', False)):
         r = subprocess.run([exe, case], capture_output=True, text=True, timeout=900,
                            env=dict(env, CPUHIP_DMA='late') if late else env)
         print('late DMA' if late else '', r.stdout)
         assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     for tile in ('1', '2', '3'):
-        for case in ('0', '1', '4', '7', '8', '10', '17'):
+        for case in ('0', '4', '8', '17'):      # (+res, GEGLU, LayerNorm fold, sub-pixel refusal; `make -C tools/cpu_check run` walks all seven)
             r = subprocess.run([exe, case], capture_output=True, text=True, timeout=600, env=dict(env, VSX_TUNE_TILE=tile))
             print('VSX_TUNE_TILE=' + tile, r.stdout)
             assert r.returncode == 0 and 'all checks passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

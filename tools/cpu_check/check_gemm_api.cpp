@@ -336,7 +336,10 @@ int main(int argc, char** argv) {
                            {"XCD grid 2x4: 128x320 tiles x 2 K slices (512x640x256)", 512, 640, 256, (2 << 8), true, 2},
                            {"XCD grid 1x8: 128x320 tiles x 4 K slices (256x640x512)", 256, 640, 512, (4 << 8), true, 1},
                            {"XCD grid 1x8: 128x320 tile x 8 K slices (128x640x1024)", 128, 640, 1024, (8 << 8), true, 1}};
+        const bool quick = getenv("CPUHIP_QUICK") != nullptr;       // the CPU test suite: the first two grids and the convolution
+        int idx = 0;
         for (const G& g : cases) {
+            if (quick && idx++ >= 2) break;
             Plain c = {g.name, g.M, g.N, g.K, true, false, false, false, false, 0, 0, 0, g.splitk};
             vsx_set_option("tile_tune", g.tune);
             vsx_set_option("xcd_walk", 0);
@@ -351,6 +354,7 @@ int main(int argc, char** argv) {
             printf("%-58s %s (gm %d -> %d)\n", "  ... bit-identical to the linear walk, grid chosen", same && gm0 == 0 && gm1 == g.want_gm ? "ok" : "FAIL", gm0, gm1);
             n_bad += same && gm0 == 0 && gm1 == g.want_gm ? 0 : 1;
         }
+        if (!quick) {
         vsx_set_option("tile_tune", (2 << 8));
         vsx_set_option("xcd_walk", 0);
         rng_state = 77u;
@@ -361,7 +365,9 @@ int main(int argc, char** argv) {
         const bool same = memcmp(a.data(), b.data(), a.size() * sizeof(half_t)) == 0;
         printf("%-58s %s (gm %d)\n", "  ... bit-identical, grid chosen", same && g_last_xcd_gm > 0 ? "ok" : "FAIL", g_last_xcd_gm);
         n_bad += same && g_last_xcd_gm > 0 ? 0 : 1;
+        }
         vsx_set_option("tile_tune", 0);
+        vsx_set_option("xcd_walk", 1);
     }
     if (only < 0 || only == nplain + 9) {
         // residual prefetch of the tile kernels BEHIND the last slab (gemm.hip, RES_LATE): ten slabs, every forced tile / ring
@@ -370,7 +376,9 @@ int main(int argc, char** argv) {
         struct T { const char* name; long tune; long M, N; };
         const T tiles[] = {{"128x160 ring 2", 2, 200, 320}, {"128x160 ring 4", 2 + 16, 200, 320}, {"128x320", 1, 200, 640},
                            {"128x128", 4, 200, 256}, {"64x128", 5, 100, 256}, {"64x64", 6, 100, 128}};
+        const bool quick = getenv("CPUHIP_QUICK") != nullptr;       // the CPU test suite: both ring depths of the 128x160 tile and the 64x64 tile
         for (const T& t : tiles) {
+            if (quick && t.tune != 2 && t.tune != 2 + 16 && t.tune != 6) continue;
             char name[128];
             snprintf(name, sizeof name, "late residual prefetch, %s tile: %ldx%ldx640 +res", t.name, t.M, t.N);
             Plain c = {name, t.M, t.N, 640, true, false, false, false, false, 0, 0, 0, false};
