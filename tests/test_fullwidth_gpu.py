@@ -175,20 +175,25 @@ def test_forward_clip_batch_shapes(models):
     B = 1 / 2 everywhere, and the largest row counts the 32-bit element offsets of the kernels see).  B = 4 goes against the
     oracle like every other shape; B = 8 (three minutes of fp32 oracle on the device) is pinned to it instead: batch items are
     independent, so the B = 8 output must equal the two B = 4 outputs of its halves up to what another kernel choice may
-    change (the same fp16 roundings almost everywhere: a few 1e-4), and each half obeys the oracle rule through the B = 4 case."""
+    change (other tiles, another summation order: within 1.5 x the fp16-storage oracle's own error), its first half is checked
+    against the oracle directly, and each half's B = 4 launch obeys the oracle rule."""
     cfg, ora, ora_dev, ora_h, prod = models
     x, txt = _inputs(8, 16, 64, 64, seed=120)
     out8 = _fwd(prod, x, 521, txt)
     assert torch.isfinite(out8).all()
     ref4 = _fwd(ora_dev, x[:4], 521, txt[:4])
     out4 = _fwd(prod, x[:4], 521, txt[:4])
-    _check('unet_B4_T16_64x64', out4, ref4, _fwd(ora_h, x[:4], 521, txt[:4]))
+    half4 = _fwd(ora_h, x[:4], 521, txt[:4])
+    _check('unet_B4_T16_64x64', out4, ref4, half4)
     out4b = _fwd(prod, x[4:], 521, txt[4:])
     e_a, e_b = rel_l2(out8[:4], out4), rel_l2(out8[4:], out4b)
-    e8 = rel_l2(out8[:4], ref4)
-    _record('unet_B8_T16_64x64', first_half_vs_B4_launch=e_a, second_half_vs_B4_launch=e_b, first_half_rel_l2_vs_fp32_oracle=e8)
-    assert e_a <= 1e-3 and e_b <= 1e-3, (e_a, e_b)
-    assert e8 <= CAP_FORWARD
+    e8, e16 = rel_l2(out8[:4], ref4), rel_l2(half4, ref4)
+    _record('unet_B8_T16_64x64', first_half_vs_B4_launch=e_a, second_half_vs_B4_launch=e_b, first_half_rel_l2_vs_fp32_oracle=e8,
+            rel_l2_fp16_oracle=e16)
+    # two fp16 evaluations of one network (other tiles, another fp32 summation order in the convolutions) differ by about the
+    # root sum of squares of their errors: measured 1.5e-3 between the two launches, each 1.3e-3 from the fp32 oracle
+    assert e_a <= 1.5 * e16 and e_b <= 1.5 * e16, (e_a, e_b, e16)
+    assert e8 <= 2 * e16 and e8 <= CAP_FORWARD, (e8, e16)
     assert not torch.equal(out8[0], out8[4])
 
 
