@@ -387,6 +387,7 @@ struct TempParams {
     int fq, fk, hw, heads, d;
     long ldq, ldkv, ldo;
     float scale;
+    int direct_out;     // option "temporal_out" = 1: round 4's store from the accumulator layout (A/B runs); default 0: staged through LDS
 };
 
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const TempParams p) {
@@ -617,20 +618,63 @@ __global__ __launch_bounds__(256) void temporal_attn_mfma_kernel(const TempParam
             o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[t], 0, 0, 0);
         }
     }
-    if (qok) {
-        half_t* orow = p.O + ((b * fq + qf_) * p.hw + site) * p.ldo + (long)(head0 + qg) * D;
+    // ---- O.  Stored from the accumulator layout, an instruction writes 8 bytes into each of 32 (frame, head) rows — ten such
+    // instructions per wave, and the kernel stalled at instruction issue a third of its time (SQ_WAIT_INST_ANY, profiles/r05_pmc_sq.txt).
+    // The tile goes through the wave's own V^T region of LDS instead (dead after the last MFMA: the LDS operations of a wave execute in
+    // order), written [query column][channel] and read back so that a lane stores 16 bytes and the G heads of a frame form one
+    // contiguous run of G * D halfs.  Staged row pitch D + 4 halfs = (D / 2 + 2) dwords = 2 mod 4: the 8-byte writes of a 16-lane group
+    // fall into 16 different bank pairs. ----
+    if (p.direct_out) {
+        if (qok) {
+            half_t* orow = p.O + ((b * fq + qf_) * p.hw + site) * p.ldo + (long)(head0 + qg) * D;
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+            for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c = t * 32 + 8 * g4 + 4 * hi;
-                if (c < D) {
-                    h4 pk;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c = t * 32 + 8 * g4 + 4 * hi;
+                    if (c < D) {
+                        h4 pk;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g4 + e] * inv);
-                    *reinterpret_cast<h4*>(orow + c) = pk;
+                        for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g4 + e] * inv);
+                        *reinterpret_cast<h4*>(orow + c) = pk;
+                    }
                 }
+        }
+        return;
+    }
+    constexpr int OSTR = D + 4;
+    static_assert(32 * OSTR <= DT * 32 * VSTR, "the staged output fits the wave's V^T tile");
+    static_assert((D / 2 + 2) % 4 == 2, "staged row pitch");
+    half_t* sO = sVT;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int c = t * 32 + 8 * g4 + 4 * hi;
+            if (c < D) {
+                h4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o[t][4 * g4 + e] * inv);
+                *reinterpret_cast<h4*>(sO + l31 * OSTR + c) = pk;
             }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    const int per_frame = G * DV;                   // 16-byte chunks of a frame's run: G heads x D / 8
+    const int total = fq * per_frame;
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+        const int u = lane + 64 * i;
+        if (u < total) {
+            const int f = u / per_frame, rem = u - f * per_frame;
+            const int g = rem / DV, ch = rem - g * DV;
+            if (head0 + g < p.heads) {
+                const half_t* src = sO + (g * fq + f) * OSTR + ch * 8;          // 8-byte aligned
+                const h4 lo4 = *reinterpret_cast<const h4*>(src), up4 = *reinterpret_cast<const h4*>(src + 4);
+                const h8 v = {lo4[0], lo4[1], lo4[2], lo4[3], up4[0], up4[1], up4[2], up4[3]};
+                st16(p.O + ((b * fq + f) * p.hw + site) * p.ldo + (long)(head0 + g) * D + ch * 8, as_u4(v));
+            }
+        }
     }
 }
 
@@ -876,6 +920,7 @@ extern "C" int vsx_temporal_attention_f16(const void* Q, const void* K, const vo
     p.Q = (const half_t*)Q; p.K = (const half_t*)K; p.V = (const half_t*)V; p.O = (half_t*)O;
     p.fq = (int)fq; p.fk = (int)fk; p.hw = (int)hw; p.heads = (int)heads; p.d = (int)d;
     p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.scale = scale;
+    p.direct_out = vsxg::gemm_option("temporal_out") == 1 ? 1 : 0;
     if (fq <= 32 && fk <= 32) {            // matrix-core kernel for the UNet's head dims
         if (d == 40) return launch_temporal_mfma<40>(p, B, (hipStream_t)stream);
         if (d == 80) return launch_temporal_mfma<80>(p, B, (hipStream_t)stream);
