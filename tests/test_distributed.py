@@ -399,3 +399,29 @@ def test_bench_plumbing_two_ranks_gloo(config, tmp_path):
     assert abs(out['value'] - clips_job * frames / (out['ms_per_step'] * 3 / 1e3)) <= 0.02 * out['value']
     assert out['ms_per_step'] >= 10.0                # the stub sleeps 10 ms per clip: the timed region really ran 3 steps
     assert 'roofline' not in out and out['vs_baseline'] is None
+
+
+@pytest.mark.parametrize('cps', [None, 1, 2])
+def test_bench_single_process_metric_arithmetic(cps, tmp_path):
+    """The default launch (`python bench.py`, one process, no torchrun) with the clip loop stubbed: one JSON line, `value` =
+    clips per step x steps x 16 frames / the timed region, the workload string names the batch, default four clips per step."""
+    import json
+    import subprocess
+    import sys
+    from util import ROOT
+    env = dict(os.environ, VSX_BENCH_STUB_CLIP='1', CUDA_VISIBLE_DEVICES='', HIP_VISIBLE_DEVICES='', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'VSX_FORCE_DISTRIBUTED'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '0', '--no-cpu-baseline']
+    if cps is not None:
+        cmd += ['--clips-per-step', str(cps)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    n = 4 if cps is None else cps
+    assert out['config']['latents'] == [n, 4, 16, 64, 64] and out['n_gpus'] == 1 and out['steps'] == 3
+    assert f'inversion (B={n})' in out['config']['workload'] and f'sampling (B={2 * n})' in out['config']['workload']
+    assert abs(out['value'] - n * 3 * 16 / (out['ms_per_step'] * 3 / 1e3)) <= 0.02 * out['value']
+    assert out['unit'] == 'frames/s' and out['dtype'] == 'f16' and out['data'] == 'synthetic' and out['scaling'] == 'weak'
