@@ -4,15 +4,19 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = the full hot path for one BATCH of clips of the headline workload (BASELINE.json configs[1]): 16-frame
-512x512 clips (latents [B,4,16,64,64], B = --clips-per-step, default 4 independent clips denoised together — the batch axis
-of the reference's own pipeline) through the SD-1.5 UNet3D + AnimateDiff motion modules, 50-step DDIM inversion (UNet batch B)
-followed by 50-step classifier-free-guided DDIM sampling (UNet batch 2B, guidance 7.5), synthetic seeded weights and inputs (no
-checkpoints/datasets exist offline), fp16 storage / fp32 accumulation.  Every clip gets the full 50 + 50 steps; nothing is
-shared between the clips of a batch but the kernel launches.  Inputs are resident in HBM before the timed region.  The same
-run also measures one clip per step (readings.R1e_one_clip_per_step: the latency mode rounds 1-4 quoted as the headline).
-With N > 1 every rank processes its own clips (clip-parallel, no data-path collective: weak scaling) and the value is the
-whole-job aggregate.
+One "step" = the full hot path for ONE clip of the headline workload — BASELINE.json configs[1] = SURVEY.md §8(d) Config 2, what
+the reference's test.py drives (test.py:102-109, pipeline_videoswap.py:376-394: one clip per option file, batch_size 1): a
+16-frame 512x512 clip (latents [1,4,16,64,64]) through the SD-1.5 UNet3D + AnimateDiff motion modules, 50-step DDIM inversion
+(UNet batch 1) followed by 50-step classifier-free-guided DDIM sampling (UNet batch 2, guidance 7.5), synthetic seeded weights
+and inputs (no checkpoints / datasets exist offline), fp16 storage / fp32 accumulation.  Inputs are resident in HBM before the
+timed region.  `value`, `ms_per_step`, `roofline` and `roofline.traffic` all belong to THAT workload over the full --steps.
+With N > 1 every rank denoises its own clips, one per step (clip-parallel = configs[4] / Config 5, no data-path collective: weak
+scaling) and the value is the whole-job aggregate.
+
+After the timed region the single-GPU run measures a second, separately labelled leg, `throughput_mode`: --throughput-clips
+(4) INDEPENDENT configs[1] clips denoised together (latents [4,4,16,64,64], the batch axis of the reference's own pipeline,
+pipeline_videoswap.py:478-550; cf. configs[4] "throughput mode"), one warm-up + --throughput-steps (3) timed steps with its own
+roofline.  It is never `value`.  --clips-per-step B makes the batch the headline of a run (and says so in `metric`).
 
 Rank 0 prints ONE JSON line: metric value = denoised frames/s end to end (R1e = frames / wall(inversion + sampling)),
 plus R1s / R2 readings, the roofline of the dominant kernel (vsx_gemm_f16: implicit-GEMM conv + GEMMs, 84 % of the
@@ -67,15 +71,15 @@ def parse():
     # hipEvent pairs around every 7th vsx_gemm_f16 launch (7 is coprime with the ~470 GEMM launches of a UNet call, so
     # every shape is sampled over the 100 calls of a clip); bracketing EVERY launch costs 5 % of the loop
     ap.add_argument('--prof-stride', type=int, default=7)
-    ap.add_argument('--clips-per-step', type=int, default=4,
-                    help='independent clips denoised TOGETHER in one step: latents [B,4,T,h,w], the batch axis of the reference\'s own '
-                         'pipeline (pipeline_videoswap.py:478-550) — UNet batch B in the inversion, 2B under CFG.  Default 4: the '
-                         'throughput mode of one 288-GB GPU (the rows of every launch x 4: 4.00 -> 4.42 (B = 2) -> 4.62 (B = 4) '
-                         'frames/s on one box, profiles/r05_bench_clips_per_step.txt); 1 = one clip at a time, which the default run '
-                         'also measures and reports as readings.R1e_one_clip_per_step')
-    ap.add_argument('--no-extra-reading', action='store_true',
-                    help='skip the extra reading (one warm-up + one timed step at the OTHER batch size: one clip per step when '
-                         '--clips-per-step > 1, two clips per step otherwise); profiling runs pass it')
+    ap.add_argument('--clips-per-step', type=int, default=1,
+                    help='independent clips denoised TOGETHER in one step of the HEADLINE: latents [B,4,T,h,w], the batch axis of the '
+                         'reference\'s own pipeline (pipeline_videoswap.py:478-550) — UNet batch B in the inversion, 2B under CFG.  '
+                         'Default 1 = SURVEY.md §8(d) Config 2, the shape the reference\'s test.py drives; B > 1 is a throughput mode '
+                         'and is named in `metric`.  The default run measures B = 4 as its own leg (`throughput_mode`)')
+    ap.add_argument('--throughput-clips', type=int, default=4,
+                    help='clips per step of the second leg (`throughput_mode`, single-GPU default-config runs only; 0 = skip)')
+    ap.add_argument('--throughput-steps', type=int, default=3, help='timed steps of the second leg (after one warm-up step)')
+    ap.add_argument('--no-extra-reading', action='store_true', help='skip the `throughput_mode` leg (profiling runs pass it)')
     args = ap.parse_args()
     if args.frames == 0:
         args.frames = 64 if args.config == 4 else 16
@@ -276,20 +280,50 @@ def long_clip_exchange(unet, shard, args, world, lh, lw):
 
 
 def gemm_traffic(frames, latent, cps):
-    """HBM bytes per vsx_gemm_f16 launch from the PMC passes of tools/pmc_by_shape.sh — only if that file was measured
-    on THIS build of the library (source digest) at the benchmark shape and batch; a stale file is not a measurement."""
+    """HBM bytes per vsx_gemm_f16 launch from the PMC passes of tools/pmc_by_shape.sh — only if the entry for THIS batch
+    (profiles/gemm_hbm_traffic.json: {"b1": {...}, "b4": {...}}, one entry per clips-per-step) was measured on THIS build of
+    the library (source digest) at the benchmark shape; a stale entry is not a measurement."""
     from videoswap_amd.build import source_digest
     path = os.path.join(ROOT, 'profiles', 'gemm_hbm_traffic.json')
     if not os.path.exists(path) or frames != 16 or latent != 64:
         return None, None, 'no PMC traffic file for this shape'
     with open(path) as f:
         t = json.load(f)
-    if int(t.get('clips_per_step', 1)) != cps:
-        return None, None, f'PMC traffic file is for {t.get("clips_per_step", 1)} clip(s) per step'
+    if 'hbm_bytes_per_launch' in t:                  # (a file with a single, unkeyed entry)
+        t = {'b%d' % int(t.get('clips_per_step', 1)): t}
+    t = t.get('b%d' % cps)
+    if t is None:
+        return None, None, f'no PMC traffic entry for {cps} clip(s) per step'
     if t.get('lib_digest') != source_digest():
-        return None, None, f'PMC traffic file is from another build ({str(t.get("lib_digest"))[:12]})'
+        return None, None, f'PMC traffic entry is from another build ({str(t.get("lib_digest"))[:12]})'
     return (round(t['hbm_bytes_per_launch']), round(t.get('algorithmic_bytes_per_launch', 0)) or None,
-            f'{t["launches"]} launches of one inversion + one CFG step')
+            f'{t["launches"]} launches of one inversion + one CFG step at {cps} clip(s) per step')
+
+
+def roofline_object(roof, elapsed, stride, traffic_key):
+    """The `roofline` object of one leg from the sampled launches (ops.prof_collect_roofline) of its timed region.
+    traffic_key: (frames, latent or -1, clips per step) for the PMC file."""
+    n_launch, gemm_ms, gemm_flop = roof['n'], roof['ms'], roof.get('flop', 0.0)
+    if not (n_launch > 0 and gemm_ms > 0):
+        return None
+    ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
+    traffic, traffic_alg, traffic_note = gemm_traffic(*traffic_key)
+    return {'bound': 'mfma', 'kernel': 'vsx_gemm_f16 (implicit-GEMM conv + GEMM, all shapes)',
+            'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_note,
+            'traffic_ratio': round(traffic / traffic_alg, 3) if traffic and traffic_alg else None,
+            'traffic_algorithmic': traffic_alg,
+            # both rooflines per launch: a launch cannot finish before max(FLOP / 2.5 PF/s, algorithmic bytes / 6.29 TB/s);
+            # the sum of those floors over the sampled launches / their measured time
+            'frac_of_attainable': round(roof['floor_ms'] / gemm_ms, 4),
+            'byte_bound_time_share': round(roof['byte_bound_ms'] / gemm_ms, 4),
+            'byte_peak_TBps': HBM_COPY_TBPS,
+            'algorithmic_GB_per_s': round(roof['bytes'] / (gemm_ms * 1e-3) / 1e9, 1),
+            'launches_sampled': int(n_launch), 'sample_stride': stride,
+            'sampling': 'every %d-th GEMM launch' % stride,
+            'avg_launch_us': round(1000.0 * gemm_ms / n_launch, 2),
+            'avg_launch_gflop': round(gemm_flop / n_launch / 1e9, 2),
+            'kernel_time_share_of_wall': round(gemm_ms * 1e-3 * stride / elapsed, 4)}
 
 
 def stack_clips(group):
@@ -313,6 +347,22 @@ def timed_clips(run_clip, batches, ddim_steps, n_steps, barrier, marks=None):
             marks.append(_event())
     barrier()
     return time.perf_counter() - t0
+
+
+def workload_string(args, cps, lh, lw, swap=False, longclip=False):
+    if cps == 1 or swap or longclip:
+        head = f'BASELINE.json configs[{args.config - 1}]: {args.frames}-frame {lw * 8}x{lh * 8} clip'
+        tail = 'the ranks share ONE clip per step' if longclip else '1 clip per GPU per step'
+    else:       # a batch is not configs[1]: it is configs[1] clips batched (cf. configs[4], the clip-parallel throughput mode)
+        head = (f'{cps} independent BASELINE.json configs[1] clips batched ({args.frames} frames, {lw * 8}x{lh * 8} each; cf. configs[4] '
+                f'"throughput mode"; NOT the shape the reference\'s test.py drives, which is one clip)')
+        tail = f'{cps} clips per GPU per step, denoised together: the batch axis of the latents'
+    return (f'{head}, SD-1.5 UNet3D + AnimateDiff motion modules, {args.ddim_steps}-step DDIM inversion (B={cps}) + '
+            f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B={2 * cps}), {tail}'
+            + ('; full swap path (VideoSwapPipeline.validation): AttentionStore during the inversion, '
+               'ED-LoRA merge + per-layer text embeddings [2,16,77,768], point-adapter residuals for '
+               'sampling steps 0-25, AttentionRefine + latent / self-attention SpatialBlenders '
+               '(use_blend), weights restored' if swap else ''))
 
 
 def main():
@@ -349,6 +399,9 @@ def main():
         cps = 1             # configs[2] carries per-clip conditions / controllers, configs[3] is ONE clip by definition
     lh, lw = args.latent_h or args.latent, args.latent_w or args.latent
     stub = os.environ.get('VSX_BENCH_STUB_CLIP') == '1'      # CPU plumbing test (tests/test_distributed.py): no model, no kernels
+    if stub and device.type == 'cuda':
+        raise SystemExit('VSX_BENCH_STUB_CLIP=1 replaces the clip loop with a sleep: refused on a box with a GPU (the line it '
+                         'prints is labelled, but must never be mistaken for a measurement)')
     pipe = None if stub else build_pipeline(device, args.frames, swap=swap)
     shard = None
     n_batches = max(args.steps, 1)
@@ -419,24 +472,21 @@ def main():
     total_flop = (ops.FlopCounter.gemm + ops.FlopCounter.attention) * world
     evals = clips_job * args.frames * 3 * args.ddim_steps                   # (1 + 2) UNet frame-evals per DDIM step
     per_clip = max(args.steps * cps, 1)
+    batch_note = '' if cps == 1 else f', {cps} independent clips denoised together per step (throughput mode: latents [{cps},4,T,h,w])'
+    metric = (f'denoised frames/sec, {args.frames}-frame 512^2 long clip @ {args.ddim_steps} DDIM steps, frame axis sharded over the GPUs '
+              '(end to end: inversion + CFG sampling)' if longclip else
+              f'denoised frames/sec, {args.frames}-frame {lw * 8}x{lh * 8} clip @ {args.ddim_steps} DDIM steps (end to end: inversion + CFG '
+              f'sampling){batch_note}')
+    if stub:
+        metric = 'STUBBED CLIP LOOP (VSX_BENCH_STUB_CLIP=1: no model, no kernels; plumbing test only) - ' + metric
     out = {
-        'metric': (f'denoised frames/sec, {args.frames}-frame 512^2 long clip @ 50 DDIM steps, frame axis sharded over the GPUs '
-                   '(end to end: inversion + CFG sampling)' if longclip else
-                   'denoised frames/sec, 16-frame 512^2 clip @ 50 DDIM steps (end to end: inversion + CFG sampling)'),
+        'metric': metric,
         'value': round(value, 4), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 2), 'higher_is_better': True,
         'scaling': 'strong' if longclip else 'weak',
         'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
         'config': {'launch': 'eager',
-                   'workload': (f'BASELINE.json configs[{args.config - 1}]: {args.frames}-frame {lw * 8}x{lh * 8} clip, SD-1.5 UNet3D + '
-                                f'AnimateDiff motion modules, {args.ddim_steps}-step DDIM inversion (B={cps}) + '
-                                f'{args.ddim_steps}-step CFG-7.5 DDIM sampling (B={2 * cps}), '
-                                + ('the ranks share ONE clip per step' if longclip else
-                                   f'{cps} clip{"s" if cps > 1 else ""} per GPU per step' + (' (denoised together: the batch axis of the latents)' if cps > 1 else ''))
-                                + ('; full swap path (VideoSwapPipeline.validation): AttentionStore during the inversion, '
-                                   'ED-LoRA merge + per-layer text embeddings [2,16,77,768], point-adapter residuals for '
-                                   'sampling steps 0-25, AttentionRefine + latent / self-attention SpatialBlenders '
-                                   '(use_blend), weights restored' if swap else '')),
+                   'workload': workload_string(args, cps, lh, lw, swap, longclip),
                    'latents': [cps, 4, args.frames, lh, lw],
                    'parallelism': (f'frame-sharded x{world} ({args.frames // world} frames per rank, exchange={args.exchange})'
                                    if longclip else f'clip-parallel x{world}')},
@@ -458,52 +508,46 @@ def main():
         out['config']['forced_distributed'] = 'VSX_FORCE_DISTRIBUTED=1: the multi-rank branches on one rank (%s)' % dist.get_backend()
     if longclip and not stub:
         out['exchange'] = long_clip_exchange(pipe.unet, shard, args, world, lh, lw)
-    n_launch, gemm_ms, gemm_flop = roof['n'], roof['ms'], roof.get('flop', 0.0)
-    if n_launch > 0 and gemm_ms > 0:
-        ach = gemm_flop / (gemm_ms * 1e-3) / 1e12
-        traffic, traffic_alg, traffic_note = gemm_traffic(
-            args.frames, args.latent if (lh == lw == args.latent and args.config == 2) else -1, cps)
-        traffic_ratio = round(traffic / traffic_alg, 3) if traffic and traffic_alg else None
+    if stub:
+        out['config']['stub'] = True
+    plain = lh == lw == args.latent and args.config == 2
+    rl = roofline_object(roof, elapsed, args.prof_stride, (args.frames, args.latent if plain else -1, cps))
+    if rl is not None:
         # footnote, not a roofline: what the power-managed clock sustains under chip-wide MFMA load on these boxes
         out['readings']['gemm_tflops_vs_sustained_clock_peak'] = {
-            'peak_sustained': MFMA_SUSTAINED_TFLOPS, 'frac': round(ach / MFMA_SUSTAINED_TFLOPS, 4),
+            'peak_sustained': MFMA_SUSTAINED_TFLOPS, 'frac': round(rl['achieved'] / MFMA_SUSTAINED_TFLOPS, 4),
             'source': 'core clock 1.75 GHz with all 256 CUs streaming MFMAs (tools/ubench/clock_probe.hip); the guide '
                       'measures 2 495 TF dense, which is the peak the roofline object prices against'}
-        out['roofline'] = {'bound': 'mfma', 'kernel': 'vsx_gemm_f16 (implicit-GEMM conv + GEMM, all shapes)',
-                           'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                           'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_note,
-                           'traffic_ratio': traffic_ratio, 'traffic_algorithmic': traffic_alg,
-                           # both rooflines per launch: a launch cannot finish before max(FLOP / 2.5 PF/s, algorithmic bytes /
-                           # 6.29 TB/s); the sum of those floors over the sampled launches / their measured time
-                           'frac_of_attainable': round(roof['floor_ms'] / gemm_ms, 4),
-                           'byte_bound_time_share': round(roof['byte_bound_ms'] / gemm_ms, 4),
-                           'byte_peak_TBps': HBM_COPY_TBPS,
-                           'algorithmic_GB_per_s': round(roof['bytes'] / (gemm_ms * 1e-3) / 1e9, 1),
-                           'launches_sampled': int(n_launch), 'sample_stride': args.prof_stride,
-                           'sampling': 'every %d-th GEMM launch' % args.prof_stride,
-                           'avg_launch_us': round(1000.0 * gemm_ms / n_launch, 2),
-                           'avg_launch_gflop': round(gemm_flop / n_launch / 1e9, 2),
-                           'kernel_time_share_of_wall': round(gemm_ms * 1e-3 * args.prof_stride / (elapsed * 1.0), 4)}
+        out['roofline'] = rl
+    tcl = args.throughput_clips
     if (rank == 0 and world == 1 and args.config == 2 and not args.no_extra_reading and not distributed and not stub
-            and device.type == 'cuda'):
-        # the OTHER batch size as an extra reading (never `value`), measured in this run after the timed region: one clip per step
-        # (the latency mode: UNet batch 1 in the inversion, 2 under CFG) beside a batched headline, two clips per step beside a
-        # single-clip one.  One warm-up step, one timed step, fresh synthetic clips.
-        other = 1 if cps > 1 else 2
-        key = 'R1e_one_clip_per_step' if other == 1 else 'R1e_two_clips_per_step'
+            and device.type == 'cuda' and tcl > 1 and tcl != cps and args.throughput_steps > 0):
+        # SECOND LEG, never `value`: `tcl` independent configs[1] clips denoised together (UNet batch tcl in the inversion, 2 tcl
+        # under CFG), fresh synthetic clips, one warm-up step + throughput_steps timed steps between barriers, its own sampled
+        # roofline and its own PMC traffic entry
         try:
+            nb = args.throughput_steps
             extra = [synthetic_clip(seed=1000 * rank + 100 + i, frames=args.frames, height=lh, width=lw, device=device)
-                     for i in range(other)]
-            one = [stack_clips(extra)]
-            run_clip(one[0], args.ddim_steps)
-            t2 = timed_clips(run_clip, one, args.ddim_steps, 1, barrier)
-            out['readings'][key] = {
-                'value': round(other * args.frames / t2, 4), 'unit': 'frames/s', 'ms_per_step': round(1e3 * t2, 1),
-                'ratio_to_value': round(other * args.frames / t2 / value, 4),
-                'note': f'latents [{other},4,T,h,w]: inversion at UNet batch {other}, CFG sampling at batch {2 * other}; a reading '
-                        'beside the headline, one warm-up step + one timed step after the timed region of this run'}
-        except Exception as e:  # a reading must never take the headline down with it
-            out['readings'][key] = {'value': None, 'note': f'failed: {e!r}'}
+                     for i in range(tcl * nb)]
+            tb = [stack_clips(extra[i * tcl:(i + 1) * tcl]) for i in range(nb)]
+            run_clip(tb[0], args.ddim_steps)
+            barrier()
+            if prof:
+                ops.prof_enable(True, args.prof_samples, stride=args.prof_stride)
+            t2 = timed_clips(run_clip, tb, args.ddim_steps, nb, barrier)
+            roof2 = ops.prof_collect_roofline(MFMA_PEAK_TFLOPS * 1e12, HBM_COPY_TBPS * 1e12) if prof else dict(n=0, ms=0.0)
+            if prof:
+                ops.prof_enable(False, 0)
+            v2 = tcl * nb * args.frames / t2
+            out['throughput_mode'] = {
+                'clips_per_step': tcl, 'value': round(v2, 4), 'unit': 'frames/s', 'steps': nb, 'warmup': 1,
+                'ms_per_step': round(1e3 * t2 / nb, 1), 'ratio_to_value': round(v2 / value, 4),
+                'latents': [tcl, 4, args.frames, lh, lw],
+                'workload': workload_string(args, tcl, lh, lw),
+                'roofline': roofline_object(roof2, t2, args.prof_stride, (args.frames, args.latent if plain else -1, tcl))}
+            del extra, tb
+        except Exception as e:  # the second leg must never take the headline down with it
+            out['throughput_mode'] = {'clips_per_step': tcl, 'value': None, 'note': f'failed: {e!r}'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and device.type == 'cuda':
         try:
             evals_per_s, threads, sample = cpu_baseline(args.cpu_frames, (lh, lw))

@@ -370,8 +370,8 @@ def test_c_abi_allgathers_replayed_across_ranks(world):
         assert torch.equal(allp[r], torch.stack(part))
 
 
-@pytest.mark.parametrize('config', [2, 4])
-def test_bench_plumbing_two_ranks_gloo(config, tmp_path):
+@pytest.mark.parametrize('config,cps_arg', [(2, None), (2, 4), (4, None)])
+def test_bench_plumbing_two_ranks_gloo(config, cps_arg, tmp_path):
     """bench.py's own multi-rank code — process-group init, barriers, max-over-ranks, the whole-job metric arithmetic and the
     ONE JSON line from rank 0 — launched the way the driver launches it (torch.distributed.run, 2 ranks), on CPU with gloo and
     the clip loop stubbed (VSX_BENCH_STUB_CLIP=1: no model, no kernels).  The driver's first SCALE run must not be the first
@@ -385,6 +385,8 @@ def test_bench_plumbing_two_ranks_gloo(config, tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
            '--config', str(config), '--no-cpu-baseline']
+    if cps_arg is not None:
+        cmd += ['--clips-per-step', str(cps_arg)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -393,7 +395,10 @@ def test_bench_plumbing_two_ranks_gloo(config, tmp_path):
     assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1 and out['higher_is_better'] is True
     frames = 64 if config == 4 else 16
     cps = out['config']['latents'][0]                # clips denoised together in one step (1 for the long clip)
-    assert cps == (1 if config == 4 else 4)
+    # default: ONE clip per GPU per step (SURVEY.md §8(d) Config 5 = one configs[1] clip per GPU); --clips-per-step 4: the batch
+    assert cps == (cps_arg or 1)
+    assert out['config']['stub'] is True and out['metric'].startswith('STUBBED')     # a stubbed line says so
+    assert 'throughput_mode' not in out              # the second leg is a single-GPU measurement
     clips_job = 3 if config == 4 else 2 * 3 * cps    # the ranks share one long clip per step / every rank its own clips
     assert out['scaling'] == ('strong' if config == 4 else 'weak')
     assert abs(out['value'] - clips_job * frames / (out['ms_per_step'] * 3 / 1e3)) <= 0.02 * out['value']
@@ -401,10 +406,11 @@ def test_bench_plumbing_two_ranks_gloo(config, tmp_path):
     assert 'roofline' not in out and out['vs_baseline'] is None
 
 
-@pytest.mark.parametrize('cps', [None, 1, 2])
+@pytest.mark.parametrize('cps', [None, 1, 2, 4])
 def test_bench_single_process_metric_arithmetic(cps, tmp_path):
     """The default launch (`python bench.py`, one process, no torchrun) with the clip loop stubbed: one JSON line, `value` =
-    clips per step x steps x 16 frames / the timed region, the workload string names the batch, default four clips per step."""
+    clips per step x steps x 16 frames / the timed region; the default is ONE clip per step = SURVEY.md §8(d) Config 2
+    (latents [1,4,16,64,64], what the reference's test.py drives), a batch is named as such in `metric` and `workload`."""
     import json
     import subprocess
     import sys
@@ -420,8 +426,15 @@ def test_bench_single_process_metric_arithmetic(cps, tmp_path):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    n = 4 if cps is None else cps
+    n = 1 if cps is None else cps
     assert out['config']['latents'] == [n, 4, 16, 64, 64] and out['n_gpus'] == 1 and out['steps'] == 3
+    assert '@ 50 DDIM steps' in out['metric'] and out['config']['stub'] is True
+    if n == 1:
+        assert 'BASELINE.json configs[1]: 16-frame 512x512 clip' in out['config']['workload'] and 'together' not in out['metric']
+    else:
+        assert f'{n} independent BASELINE.json configs[1] clips batched' in out['config']['workload']
+        assert f'{n} independent clips denoised together' in out['metric']
+    assert 'throughput_mode' not in out              # (stubbed / no GPU: the second leg does not run)
     assert f'inversion (B={n})' in out['config']['workload'] and f'sampling (B={2 * n})' in out['config']['workload']
     assert abs(out['value'] - n * 3 * 16 / (out['ms_per_step'] * 3 / 1e3)) <= 0.02 * out['value']
     assert out['unit'] == 'frames/s' and out['dtype'] == 'f16' and out['data'] == 'synthetic' and out['scaling'] == 'weak'

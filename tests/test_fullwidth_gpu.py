@@ -170,13 +170,12 @@ def test_forward_benchmark_shape(models):
 
 
 def test_forward_clip_batch_shapes(models):
-    """(2b) the UNet batches of bench.py's default workload, four clips per step: B = 4 in the inversion, B = 8 under CFG, T = 16,
+    """(2b) the UNet batches of bench.py's throughput leg, four clips per step: B = 4 in the inversion, B = 8 under CFG, T = 16,
     64x64 (M = 262 144 / 524 288 rows at the top level, 16 384 / 32 768 at 16x16, 4 096 / 8 192 at 8x8 — other tile choices than
-    B = 1 / 2 everywhere, and the largest row counts the 32-bit element offsets of the kernels see).  B = 4 goes against the
-    oracle like every other shape; B = 8 (three minutes of fp32 oracle on the device) is pinned to it instead: batch items are
-    independent, so the B = 8 output must equal the two B = 4 outputs of its halves up to what another kernel choice may
-    change (other tiles, another summation order: within 1.5 x the fp16-storage oracle's own error), its first half is checked
-    against the oracle directly, and each half's B = 4 launch obeys the oracle rule."""
+    B = 1 / 2 everywhere, and the largest row counts the 32-bit element offsets of the kernels see).  The B = 4 launch and BOTH
+    halves of the B = 8 launch go against the fp32 oracle under the full rule (the oracle runs the two halves as two B = 4
+    forwards: batch items are independent and a B = 8 fp32 forward does not fit its attention scores); round 5 compared the
+    second half only with the product's own B = 4 launch."""
     cfg, ora, ora_dev, ora_h, prod = models
     x, txt = _inputs(8, 16, 64, 64, seed=120)
     out8 = _fwd(prod, x, 521, txt)
@@ -185,15 +184,14 @@ def test_forward_clip_batch_shapes(models):
     out4 = _fwd(prod, x[:4], 521, txt[:4])
     half4 = _fwd(ora_h, x[:4], 521, txt[:4])
     _check('unet_B4_T16_64x64', out4, ref4, half4)
-    out4b = _fwd(prod, x[4:], 521, txt[4:])
-    e_a, e_b = rel_l2(out8[:4], out4), rel_l2(out8[4:], out4b)
-    e8, e16 = rel_l2(out8[:4], ref4), rel_l2(half4, ref4)
-    _record('unet_B8_T16_64x64', first_half_vs_B4_launch=e_a, second_half_vs_B4_launch=e_b, first_half_rel_l2_vs_fp32_oracle=e8,
-            rel_l2_fp16_oracle=e16)
+    _check('unet_B8_T16_64x64_first_half', out8[:4], ref4, half4, extra=dict(vs_B4_launch=rel_l2(out8[:4], out4)))
     # two fp16 evaluations of one network (other tiles, another fp32 summation order in the convolutions) differ by about the
     # root sum of squares of their errors: measured 1.5e-3 between the two launches, each 1.3e-3 from the fp32 oracle
-    assert e_a <= 1.5 * e16 and e_b <= 1.5 * e16, (e_a, e_b, e16)
-    assert e8 <= 2 * e16 and e8 <= CAP_FORWARD, (e8, e16)
+    assert rel_l2(out8[:4], out4) <= 1.5 * rel_l2(half4, ref4)
+    del ref4, half4, out4
+    ref4b = _fwd(ora_dev, x[4:], 521, txt[4:])
+    half4b = _fwd(ora_h, x[4:], 521, txt[4:])
+    _check('unet_B8_T16_64x64_second_half', out8[4:], ref4b, half4b)
     assert not torch.equal(out8[0], out8[4])
 
 
@@ -290,8 +288,21 @@ def test_forward_outlier_stress(models):
                     m.bump_weights_epoch()
 
 
+_ORACLE_LOOPS = {}      # (id(model), key) -> (inverted, final): the 50 + 50 oracle loops cost 45 s and two tests need the same ones
+
+
 @torch.no_grad()
-def _oracle_loops(model, x, txt, neg, steps, guidance=7.5):
+def _oracle_loops(model, x, txt, neg, steps, guidance=7.5, cache_key=None):
+    if cache_key is not None and (id(model), cache_key) in _ORACLE_LOOPS:
+        return _ORACLE_LOOPS[(id(model), cache_key)]
+    r = _oracle_loops_uncached(model, x, txt, neg, steps, guidance)
+    if cache_key is not None:
+        _ORACLE_LOOPS[(id(model), cache_key)] = r
+    return r
+
+
+@torch.no_grad()
+def _oracle_loops_uncached(model, x, txt, neg, steps, guidance=7.5):
     from oracle import pipeline as opipe
     dev, dt = next(model.parameters()).device, next(model.parameters()).dtype
     lat = opipe.invert(model, x.to(dev, dt), txt.to(dev, dt), steps)
@@ -313,6 +324,11 @@ def _product_loops(prod, x, txt, neg, steps, guidance=7.5):
     return inv.float().cpu(), out.float().cpu()
 
 
+def _loop_case(steps):
+    x, txt = _inputs(1, 16, 64, 64, seed=107 + steps)
+    return x, txt, torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(7))
+
+
 @pytest.mark.parametrize('steps', [5, 50])
 def test_sequential_steps_full_width(models, steps):
     """(5) `steps` inversion steps (B = 1) + `steps` CFG-7.5 sampling steps (B = 2) at T = 16, 64x64: config 2 of
@@ -321,13 +337,12 @@ def test_sequential_steps_full_width(models, steps):
     The final latents obey the same <= 2x rule against the fp16-storage oracle pushed through the same loops (fp16
     error compounds over sequential UNet calls)."""
     cfg, ora, ora_dev, ora_h, prod = models
-    x, txt = _inputs(1, 16, 64, 64, seed=107 + steps)
-    neg = torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(7))
+    x, txt, neg = _loop_case(steps)
     t0 = time.time()
-    inv_ref, out_ref = _oracle_loops(ora_dev, x, txt, neg, steps)
+    inv_ref, out_ref = _oracle_loops(ora_dev, x, txt, neg, steps, cache_key=('loops', steps))
     t_ref = time.time() - t0
     t0 = time.time()
-    inv_h, out_h = _oracle_loops(ora_h, x, txt, neg, steps)
+    inv_h, out_h = _oracle_loops(ora_h, x, txt, neg, steps, cache_key=('loops', steps))
     t_h = time.time() - t0
     _product_loops(prod, x, txt, neg, 1)          # first-call costs (weight packing, text K/V) outside the timing
     torch.cuda.synchronize()
@@ -361,6 +376,41 @@ def test_clips_denoised_together_match_the_oracle_clip_by_clip(models):
         inv_ref, out_ref = _oracle_loops(ora_dev, xs[i], txts[i], negs[i], 3)
         inv_h, out_h = _oracle_loops(ora_h, xs[i], txts[i], negs[i], 3)
         _check_loops(f'loops_3+3_T8_64x64_clip{i}_of_a_batch_of_{NC}', inv_p[i:i + 1], out_p[i:i + 1], inv_ref, out_ref, inv_h, out_h)
+    assert not torch.equal(out_p[0], out_p[1])
+
+
+def test_four_clips_batched_at_depth_50_steps_T16(models):
+    """(5d) bench.py's throughput leg at its real depth (the batched loop was pinned at 3 + 3 steps, T = 8):
+    FOUR clips denoised together through 50 inversion steps (UNet batch 4) + 50 CFG-7.5 sampling steps (batch 8) at T = 16, 64x64
+    (pipeline_videoswap.py:677-710, :555-601 with the batch axis of :478-550).  Clip 0 is the clip of the 50 + 50 single-clip case
+    above: it goes against the fp32 oracle loop and the fp16-storage yardstick under `_check_loops` (the oracle loops are shared
+    with that test: 45 s not spent twice).  Clips 1 - 3 go against the product's own SINGLE-clip runs of the same inputs — 200
+    sequential UNet calls each way — within 1.5 x the yardstick's error (two fp16 evaluations of one network: other tiles,
+    another fp32 summation order; 135 s of fp32 oracle not spent), and nothing may leak between the clips of a batch."""
+    cfg, ora, ora_dev, ora_h, prod = models
+    steps, NC = 50, 4
+    x0, txt0, neg0 = _loop_case(steps)
+    xs, txts, negs = [x0], [txt0], [neg0]
+    for i in range(1, NC):
+        x, txt = _inputs(1, 16, 64, 64, seed=171 + i)
+        xs.append(x); txts.append(txt)
+        negs.append(torch.randn(1, 77, 768, generator=torch.Generator().manual_seed(27 + i)))
+    t0 = time.time()
+    inv_p, out_p = _product_loops(prod, torch.cat(xs), torch.cat(txts), torch.cat(negs), steps)
+    t_batch = time.time() - t0
+    assert inv_p.shape[0] == NC and out_p.shape[0] == NC
+    inv_ref, out_ref = _oracle_loops(ora_dev, x0, txt0, neg0, steps, cache_key=('loops', steps))
+    inv_h, out_h = _oracle_loops(ora_h, x0, txt0, neg0, steps, cache_key=('loops', steps))
+    _check_loops(f'loops_{steps}+{steps}_T16_64x64_clip0_of_a_batch_of_{NC}', inv_p[:1], out_p[:1], inv_ref, out_ref, inv_h, out_h,
+                 extra=dict(wall_s_product_batch=t_batch))
+    e16_inv, e16_out = rel_l2(inv_h, inv_ref), rel_l2(out_h, out_ref)
+    for i in range(1, NC):
+        inv_1, out_1 = _product_loops(prod, xs[i], txts[i], negs[i], steps)
+        e_inv, e_out = rel_l2(inv_p[i:i + 1], inv_1), rel_l2(out_p[i:i + 1], out_1)
+        _record(f'loops_{steps}+{steps}_T16_64x64_clip{i}_of_a_batch_of_{NC}_vs_single_clip_run', inversion_rel_l2=e_inv,
+                final_rel_l2=e_out, yardstick_inversion=e16_inv, yardstick_final=e16_out, final_cosine=cosine(out_p[i:i + 1], out_1))
+        assert e_inv <= 1.5 * e16_inv + 1e-4 and e_out <= 1.5 * e16_out + 1e-4, (i, e_inv, e_out, e16_inv, e16_out)
+        assert e_out <= CAP_FINAL_LATENTS
     assert not torch.equal(out_p[0], out_p[1])
 
 

@@ -101,8 +101,30 @@ def time_once(fn, reps):
     return a.elapsed_time(b) / reps
 
 
+_LIBS = {}          # --libs: variant name -> typed ctypes handle of another BUILD of the library (lib/libvsx_<name>.so)
+
+
+def load_build(name):
+    """'product' = the library the product loads; anything else = lib/libvsx_<name>.so (python -m videoswap_amd.build --from-git
+    <name> <rev>: the kernel sources of another revision), typed like the product's and swapped in under videoswap_amd.ops for the
+    launches of that variant.  Same ABI required."""
+    import ctypes
+    from videoswap_amd import _lib
+    if name == 'product':
+        return _lib.load()
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), f'libvsx_{name}.so'))
+    for fn_name, (restype, argtypes) in _lib.PROTOTYPES.items():
+        fn = getattr(lib, fn_name)
+        fn.restype, fn.argtypes = restype, argtypes
+    assert lib.vsx_abi_version() == _lib.VSX_ABI_VERSION, 'the other build must speak the same ABI'
+    return lib
+
+
 def apply(v):
-    """variant = (name, gemm_pp[, pp_sched[, tile_tune[, xcd_walk]]])"""
+    """variant = (name, gemm_pp[, pp_sched[, tile_tune[, xcd_walk]]]); with --libs the name selects the BUILD"""
+    if _LIBS:
+        from videoswap_amd import _lib
+        _lib._lib = _LIBS[v[0]]
     ops.set_option('gemm_pp', v[1])
     ops.set_option('pp_sched', v[2] if len(v) > 2 else 0)
     ops.set_option('tile_tune', v[3] if len(v) > 3 else 0)
@@ -121,6 +143,8 @@ def main():
     ap.add_argument('--auto-scheds', default='', help='comma-separated pp_sched values under the automatic dispatch (gemm_pp = 1)')
     ap.add_argument('--bm', type=int, default=256, choices=(128, 256), help='row tile of the --scheds comparison')
     ap.add_argument('--kinds', default='', help="comma-separated subset of plain,geglu,conv (default: all)")
+    ap.add_argument('--libs', default='', help='comma-separated builds, first = baseline column: "r5,product" compares lib/libvsx_r5.so '
+                    '(python -m videoswap_amd.build --from-git r5 <rev>) with the product library under the automatic dispatch')
     args = ap.parse_args()
     variants = [('tile', 0, 0), ('pp256', 2, 0), ('pp128', 3, 0), ('auto', 1, 0)]
     if args.scheds:
@@ -134,9 +158,16 @@ def main():
         variants[0] = ('tile',) + tuple(int(x) for x in args.base.split(':')[1:])
     if args.auto_scheds:        # the product's own dispatch (gemm_pp = 1) under different pp_sched bits; 'tile' stays the baseline column
         variants = [('tile', 0, 0)] + [(f'auto/s{int(n)}', 1, int(n)) for n in args.auto_scheds.split(',')]
+    if args.libs:               # two BUILDS of the library, both under the product's dispatch; the first is the baseline column
+        names = args.libs.split(',')
+        for n in names:
+            _LIBS[n] = load_build(n)
+        variants = [(n, 1, 0) for n in names]
+        print('# builds: ' + ', '.join(f'{n} = {_LIBS[n].vsx_source_digest().decode()[:16]}' for n in names))
+    base = variants[0][0]
     print(f'# B={args.batch} T=16 64x64; median of {args.rounds} rounds x {args.reps} launches; times in us')
     print(f'{"shape":44s} {"n":>3s} ' + ' '.join(f'{v[0]:>9s}' for v in variants) + '   best TF/s  speedup  fwd-ms tile -> best')
-    tot_old = tot_best = 0.0
+    tot_old = tot_best = tot_second = 0.0
     level_of = {16 * args.batch * hw * hw: hw for hw in (64, 32, 16, 8)}     # rows of a plain GEMM -> latent side of its level
     for kind, name, a, count in shapes(args.batch):
         if args.kinds and kind not in args.kinds.split(','):
@@ -154,9 +185,9 @@ def main():
             apply(v)
             outs[v[0]] = fns[v[0]]()
         torch.cuda.synchronize()
-        bad = [k for k, o in outs.items() if not torch.equal(o, outs['tile'])]
+        bad = [k for k, o in outs.items() if not torch.equal(o, outs[base])]
         if bad:         # another K order (pp_sched bit 4) is not bit-identical: report how far it is
-            ref = outs['tile'].float()
+            ref = outs[base].float()
             dev = {k: float((outs[k].float() - ref).norm() / ref.norm()) for k in bad}
             print(f'# {name}: variants differing from the tile kernels (rel-L2): ' + ', '.join(f'{k} {v:.2e}' for k, v in dev.items()))
         del outs
@@ -168,11 +199,19 @@ def main():
                 ts[v[0]].append(time_once(fns[v[0]], args.reps))
         med = {k: sorted(x)[len(x) // 2] * 1000.0 for k, x in ts.items()}
         best = min(med, key=med.get)
-        tot_old += med['tile'] * count / 1000.0
+        tot_old += med[base] * count / 1000.0
         tot_best += med[best] * count / 1000.0
         print(f'{name:44s} {count:3d} ' + ' '.join(f'{med[v[0]]:9.1f}' for v in variants) +
-              f'   {flop / med[best] / 1e6:7.1f}  {med["tile"] / med[best]:6.2f}x  {best:9s}'
-              f' {med["tile"] * count / 1000:6.2f} -> {med[best] * count / 1000:6.2f}', flush=True)
+              f'   {flop / med[best] / 1e6:7.1f}  {med[base] / med[best]:6.2f}x  {best:9s}'
+              f' {med[base] * count / 1000:6.2f} -> {med[best] * count / 1000:6.2f}', flush=True)
+        if _LIBS and len(variants) == 2:
+            tot_second += med[variants[1][0]] * count / 1000.0
+    if _LIBS:
+        from videoswap_amd import _lib
+        _lib._lib = _LIBS.get('product', _lib._lib)
+        if len(variants) == 2:
+            print(f'# GEMM time per forward (listed shapes): {variants[0][0]} {tot_old:.2f} ms, {variants[1][0]} {tot_second:.2f} ms')
+        return
     apply(('auto', 1))
     print(f'# GEMM time per forward (listed shapes): tile kernels {tot_old:.2f} ms, best-of {tot_best:.2f} ms')
 

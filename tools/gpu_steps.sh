@@ -18,7 +18,9 @@
 #   bench2         python bench.py --clips-per-step 2 ...   (two clips denoised together)
 #   smoke          __graft_entry__.smoke()
 #   trace          rocprofv3 --kernel-trace --stats of a 10 + 10-step clip -> TAG_kernel_stats.txt
-#   pmcshape       tools/pmc_by_shape.sh       per-shape fabric traffic (also refreshes profiles/gemm_hbm_traffic.json)
+#   pmcshape[:N]   tools/pmc_by_shape.sh       per-shape fabric traffic at N clips per step (default 1); the entry b<N> is merged into
+#                                              profiles/gemm_hbm_traffic.json on the box (later bench steps of the SAME call see it) and comes
+#                                              back as gpurun_out/TAG_gemm_hbm_traffic_bN.json: merge it here with tools/pmc_by_shape.py --merge
 #   pmcsq          tools/pmc_sq.sh             SQ counters (MFMA busy, LDS conflicts)
 #   attn           tools/attn_ab.py
 #   train          tools/train_bench.py
@@ -71,7 +73,7 @@ for STEP in "$@"; do
     bench448)
       timeout 400 python bench.py --latent-h 56 --latent-w 96 --steps 1 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench448.txt 2>&1; show bench448 1 600 ;;
     bench2)
-      timeout 400 python bench.py --clips-per-step 2 --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench2.txt 2>&1; show bench2 1 1500 ;;
+      timeout 400 python bench.py --clips-per-step 2 --steps 2 --warmup 1 --no-cpu-baseline --no-extra-reading > $O/${TAG}_bench2.txt 2>&1; show bench2 1 1500 ;;
     benchenv:*)       # benchenv:NAME=VALUE:clips — one quick bench line under an environment switch (in-situ A/B of an option)
       A=${STEP#benchenv:}; E=${A%%:*}; N=${A##*:}
       env $E timeout 600 python bench.py --clips-per-step $N --steps 2 --warmup 1 --no-cpu-baseline --no-extra-reading > $O/${TAG}_benchenv.txt 2>&1
@@ -88,10 +90,19 @@ for STEP in "$@"; do
       [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $O/${TAG}_kernel_stats.txt 2>&1
       find $O/${TAG}_prof -type f -size +4M -delete 2>/dev/null
       head -n 24 $O/${TAG}_kernel_stats.txt | cut -c1-180; tail -n 3 $O/${TAG}_kernel_stats.txt | cut -c1-200 ;;
-    pmcshape)
-      bash tools/pmc_by_shape.sh ${TAG}_pmc_shape > $O/${TAG}_pmc_shape.txt 2>&1; show pmc_shape 2
-      cp $O/${TAG}_pmc_shape/gemm_hbm_traffic.json $R/profiles/gemm_hbm_traffic.json 2>/dev/null
-      cp $O/${TAG}_pmc_shape/gemm_hbm_traffic.json $O/${TAG}_gemm_hbm_traffic.json 2>/dev/null ;;
+    trace:*)                  # trace:N = the same at N clips per step -> TAG_kernel_stats_bN.txt
+      N=${STEP#trace:}
+      ( cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_b$N -o r05 -- python $R/bench.py --clips-per-step $N --steps 1 --warmup 0 --ddim-steps 10 --no-cpu-baseline --no-extra-reading --prof-samples 0 > $O/${TAG}_prof_b$N.log 2>&1 )
+      DB=$(find $O/${TAG}_prof_b$N -name '*.db' | head -n 1)
+      [ -n "$DB" ] && python tools/rocpd_summary.py $DB > $O/${TAG}_kernel_stats_b$N.txt 2>&1
+      find $O/${TAG}_prof_b$N -type f -size +4M -delete 2>/dev/null
+      head -n 24 $O/${TAG}_kernel_stats_b$N.txt | cut -c1-180; tail -n 3 $O/${TAG}_kernel_stats_b$N.txt | cut -c1-200 ;;
+    pmcshape|pmcshape:*)      # pmcshape:N = N clips per step (default 1 = the headline); the entry lands in gpurun_out/TAG_gemm_hbm_traffic_bN.json
+      N=1; [ "$STEP" != pmcshape ] && N=${STEP#pmcshape:}
+      bash tools/pmc_by_shape.sh ${TAG}_pmc_shape_b$N --clips-per-step $N > $O/${TAG}_pmc_shape_b$N.txt 2>&1; show pmc_shape_b$N 2
+      cp $O/${TAG}_pmc_shape_b$N/gemm_hbm_traffic.json $O/${TAG}_gemm_hbm_traffic_b$N.json 2>/dev/null
+      cp $O/${TAG}_pmc_shape_b$N/by_shape.txt $O/${TAG}_gemm_traffic_by_shape_b$N.txt 2>/dev/null
+      python tools/pmc_by_shape.py --merge $R/profiles/gemm_hbm_traffic.json $O/${TAG}_gemm_hbm_traffic_b$N.json ;;
     pmcsq)
       bash tools/pmc_sq.sh ${TAG}_pmc_sq; cat $O/${TAG}_pmc_sq/passes.txt; head -n 24 $O/${TAG}_pmc_sq/summary.txt | cut -c1-200 ;;
     attn)

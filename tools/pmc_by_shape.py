@@ -112,17 +112,41 @@ def main(root):
     import json
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from videoswap_amd.build import source_digest
-    with open(os.path.join(root, 'gemm_hbm_traffic.json'), 'w') as f:
-        meta = {}
-        if os.path.exists(os.path.join(root, 'gemm_log.txt.meta.json')):
-            meta = json.load(open(os.path.join(root, 'gemm_log.txt.meta.json')))
-        json.dump({'kernel': 'vsx_gemm_f16 (all shapes of one inversion step + one CFG step)', 'launches': n,
-                   'clips_per_step': meta.get('clips_per_step', 1),
-                   'lib_digest': source_digest(), 'hbm_bytes_per_launch': tot_hbm / n,
-                   'algorithmic_bytes_per_launch': tot_alg / n, 'ratio': tot_hbm / tot_alg,
-                   'note': 'FETCH_SIZE x 2 (gfx950 reports half the bytes of wide coalesced reads) + WRITE_SIZE, separate '
-                           '--pmc passes, tools/pmc_by_shape.sh'}, f, indent=1)
+    meta = {}
+    if os.path.exists(os.path.join(root, 'gemm_log.txt.meta.json')):
+        meta = json.load(open(os.path.join(root, 'gemm_log.txt.meta.json')))
+    cps = int(meta.get('clips_per_step', 1))
+    entry = {'kernel': 'vsx_gemm_f16 (all shapes of one inversion step + one CFG step)', 'launches': n,
+             'clips_per_step': cps,
+             'lib_digest': source_digest(), 'hbm_bytes_per_launch': tot_hbm / n,
+             'algorithmic_bytes_per_launch': tot_alg / n, 'ratio': tot_hbm / tot_alg,
+             'note': 'FETCH_SIZE x 2 (gfx950 reports half the bytes of wide coalesced reads) + WRITE_SIZE, separate '
+                     '--pmc passes, tools/pmc_by_shape.sh'}
+    with open(os.path.join(root, 'gemm_hbm_traffic.json'), 'w') as f:      # one entry per clips-per-step: {"b1": ..., "b4": ...}
+        json.dump({'b%d' % cps: entry}, f, indent=1)
+
+
+def merge(dst, sources):
+    """python tools/pmc_by_shape.py --merge profiles/gemm_hbm_traffic.json gpurun_out/<tag>_gemm_hbm_traffic_b1.json ... :
+    the entries of the source files replace the entries of the same batch in dst (bench.py reads dst, keyed by batch)."""
+    import json
+    cur = {}
+    if os.path.exists(dst):
+        cur = json.load(open(dst))
+        if 'hbm_bytes_per_launch' in cur:            # round-5 layout: one unkeyed entry
+            cur = {'b%d' % int(cur.get('clips_per_step', 1)): cur}
+    for src in sources:
+        new = json.load(open(src))
+        if 'hbm_bytes_per_launch' in new:
+            new = {'b%d' % int(new.get('clips_per_step', 1)): new}
+        cur.update(new)
+    with open(dst, 'w') as f:
+        json.dump(dict(sorted(cur.items())), f, indent=1)
+    print({k: (v['lib_digest'][:12], round(v['ratio'], 3)) for k, v in cur.items()})
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 2 and sys.argv[1] == '--merge':
+        merge(sys.argv[2], sys.argv[3:])
+        sys.exit(0)
     main(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc_shape')

@@ -13,8 +13,11 @@ fork of the persistent GEMM (no gain: profiles/r03_gemm_sched_ab_b2.txt, r03_gem
 """
 import hashlib
 import os
+import re
+import shutil
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -99,6 +102,95 @@ def _compile(src, digest, variant=None):
     return obj
 
 
+LLVM_BIN = os.environ.get('VSX_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+# kernels whose inner loops count their own `vmcnt` entries (LDS-DMA pieces, residual ring): a scratch reload is one more
+# VMEM operation in that queue, so these must compile without spills and without a private segment (gemm_pp.hip:33-37)
+# (matched on the MANGLED names: gemm_kernelILi256E... = gemm_kernel<256, ...>)
+NO_SCRATCH = ('gemm_pp_kernel', 'flash_attn_kernel', 'gemm_kernelILi256E')
+
+
+def parse_kernel_notes(text):
+    """AMDGPU metadata note (llvm-readelf --notes) -> {mangled kernel name: {vgpr_count, agpr_count, sgpr_count,
+    vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size, group_segment_fixed_size}}."""
+    keys = ('vgpr_count', 'agpr_count', 'sgpr_count', 'vgpr_spill_count', 'sgpr_spill_count',
+            'private_segment_fixed_size', 'group_segment_fixed_size')
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r'^\s+(-\s+)?\.(\w+):\s*(\S.*)?$', line)
+        if not m:
+            continue
+        if m.group(1) and re.match(r'^  - ', line):        # a new entry of amdhsa.kernels (the nested .args entries sit deeper)
+            cur = {}
+        if cur is None:
+            continue
+        key, val = m.group(2), (m.group(3) or '').strip()
+        if key == 'name' and re.match(r'^    \.name:', line):
+            out[val] = cur
+        elif key in keys and re.match(r'^  (- |  )\.', line):
+            cur[key] = int(val)
+    return out
+
+
+def kernel_resources(lib=None):
+    """Register / scratch figures of every kernel in the built library, from the code objects' own metadata notes
+    (llvm-objdump --offloading extracts the gfx950 bundles, llvm-readelf --notes prints them)."""
+    lib = lib or LIB
+    objdump, readelf = os.path.join(LLVM_BIN, 'llvm-objdump'), os.path.join(LLVM_BIN, 'llvm-readelf')
+    tmp = tempfile.mkdtemp(prefix='vsx_co_')
+    try:
+        copy = os.path.join(tmp, 'lib.so')
+        shutil.copy(lib, copy)
+        r = subprocess.run([objdump, '--offloading', copy], capture_output=True, text=True, cwd=tmp)
+        if r.returncode != 0:
+            raise RuntimeError(f'llvm-objdump --offloading failed:\n{r.stderr}')
+        res = {}
+        for name in sorted(os.listdir(tmp)):
+            if 'gfx950' not in name:
+                continue
+            r = subprocess.run([readelf, '--notes', os.path.join(tmp, name)], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f'llvm-readelf --notes failed on {name}:\n{r.stderr}')
+            res.update(parse_kernel_notes(r.stdout))
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def demangle(names):
+    """pretty names for messages only (binutils' c++filt when there is one; the checks match mangled names)"""
+    filt = shutil.which('c++filt') or shutil.which('llvm-cxxfilt')
+    out = []
+    if filt and names:
+        r = subprocess.run([filt], input='\n'.join(names), capture_output=True, text=True)
+        out = r.stdout.splitlines() if r.returncode == 0 else []
+    return dict(zip(names, out if len(out) == len(names) else names))
+
+
+def scratch_offenders(resources, patterns=NO_SCRATCH):
+    """[(demangled name, vgpr spills, private segment bytes)] of the kernels matching `patterns` that spill or own a
+    private segment."""
+    pretty = demangle(list(resources))
+    bad = []
+    for name, r in resources.items():
+        if not any(p in name for p in patterns):
+            continue
+        if r.get('vgpr_spill_count', 0) or r.get('private_segment_fixed_size', 0):
+            bad.append((pretty[name], r.get('vgpr_spill_count', 0), r.get('private_segment_fixed_size', 0)))
+    return sorted(bad)
+
+
+def check_no_scratch(lib=None):
+    """Post-link check: the hand-scheduled kernels must not touch scratch."""
+    res = kernel_resources(lib)
+    if not res:
+        raise RuntimeError('no kernel metadata found in ' + (lib or LIB))
+    bad = scratch_offenders(res)
+    if bad:
+        raise RuntimeError('kernels that must not use scratch do:\n' + '\n'.join(
+            f'  {n}: {s} VGPRs spilled, {b} B private segment' for n, s, b in bad))
+    return res
+
+
 def build(force=False, verbose=True, variant=None):
     os.makedirs(OBJDIR, exist_ok=True)
     lib = lib_path(variant)
@@ -117,11 +209,65 @@ def build(force=False, verbose=True, variant=None):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    if os.environ.get('VSX_ALLOW_SCRATCH') != '1':     # development builds may look at a spilling candidate; the product may not
+        try:
+            check_no_scratch(lib)
+        except RuntimeError:
+            os.replace(lib, lib + '.rejected')         # never leave a library behind that the check refused
+            raise
     if verbose:
         print(f'[vsx] built {lib}')
     return lib
 
 
+def build_from_git(name, rev, verbose=True):
+    """lib/libvsx_<name>.so from the kernel sources of git revision `rev` (A/B of two BUILDS inside one process on the GPU box:
+    tools/gemm_ab.py --libs product,<name>).  The old sources are extracted into lib/src_<name>/ (git-ignored with the rest of
+    lib/); nothing of them is tracked, and the product never loads such a library (VSX_LIB_VARIANT / the tools only)."""
+    src = os.path.join(LIBDIR, f'src_{name}')
+    inc = os.path.join(src, 'include')
+    shutil.rmtree(src, ignore_errors=True)
+    os.makedirs(inc)
+    ls = subprocess.run(['git', '-C', ROOT, 'ls-tree', '--name-only', rev, 'videoswap_amd/csrc/'], capture_output=True, text=True, check=True)
+    files = [f for f in ls.stdout.split() if f.endswith(('.hip', '.cpp', '.h'))] + ['include/vsx.h']
+    for f in files:
+        blob = subprocess.run(['git', '-C', ROOT, 'show', f'{rev}:{f}'], capture_output=True, check=True).stdout
+        with open(os.path.join(inc if f.startswith('include/') else src, os.path.basename(f)), 'wb') as out:
+            out.write(blob)
+    objdir = os.path.join(LIBDIR, f'obj_{name}')
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f if f not in (os.path.join(ROOT, 'include'), CSRC) else (inc if f.endswith('include') else src) for f in FLAGS]
+    sources = [n for n in SOURCES if os.path.exists(os.path.join(src, n))]
+
+    def one(n):
+        obj = os.path.join(objdir, n + '.o')
+        extra = [f'-DVSX_SOURCE_DIGEST="git-{rev[:12]}"'] if n == 'api.cpp' else []
+        r = subprocess.run([HIPCC] + flags + extra + ['-c', os.path.join(src, n), '-o', obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {n} of {rev}:\n{r.stderr}')
+        return obj
+    with ThreadPoolExecutor(max_workers=len(sources)) as ex:
+        objs = list(ex.map(one, sources))
+    lib = lib_path(name)
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + ['-ldl'], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stderr}')
+    if verbose:
+        print(f'[vsx] built {lib} from {rev}')
+    return lib
+
+
 if __name__ == '__main__':
+    if '--from-git' in sys.argv:                       # --from-git NAME REV
+        _i = sys.argv.index('--from-git')
+        build_from_git(sys.argv[_i + 1], sys.argv[_i + 2])
+        sys.exit(0)
     _variant = sys.argv[sys.argv.index('--variant') + 1] if '--variant' in sys.argv else None
+    if '--resources' in sys.argv:                      # register / scratch table of the built library
+        _res = kernel_resources(lib_path(_variant))
+        _names = demangle(list(_res))
+        for _k, _r in sorted(_res.items(), key=lambda kv: _names[kv[0]]):
+            print(f"{_r.get('vgpr_count', 0):4d} v {_r.get('agpr_count', 0):4d} a {_r.get('vgpr_spill_count', 0):3d} spilled "
+                  f"{_r.get('private_segment_fixed_size', 0):5d} B scratch {_r.get('group_segment_fixed_size', 0):7d} B LDS  {_names[_k]}")
+        sys.exit(0)
     build(force='--force' in sys.argv, variant=_variant)

@@ -595,9 +595,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
         for (int i = 0; i < TM; ++i) {
             const int m = mb + wr * WM + i * 32 + l31;
             if (m >= Mi) continue;
-            half_t* crow = Cb + (unsigned)m * (unsigned)ldc;
-            const half_t* rrow = Rb ? Rb + (unsigned)m * (unsigned)ldr : nullptr;
-            const half_t* rv = p.rowvec ? p.rowvec + ((unsigned)m / (unsigned)p.rows_per_vec) * (unsigned)Ni : nullptr;
+            // Row bases as 32-bit BYTE offsets from wave-uniform pointers (the host guarantees M * ldc, M * ldr < 2^31 elements):
+            // the accesses take the scalar-base form, and a row costs three registers instead of three 64-bit pointers — the
+            // 16-wave kernel (128 registers) spilled one of them (videoswap_amd/build.py refuses that now).
+            const unsigned cbyte = (unsigned)m * (unsigned)ldc * 2u;
+            const unsigned rbyte = (unsigned)m * (unsigned)ldr * 2u;
+            const unsigned vbyte = p.rowvec ? ((unsigned)m / (unsigned)p.rows_per_vec) * (unsigned)Ni * 2u : 0u;
+            const bool rrow = Rb != nullptr, rv = p.rowvec != nullptr;
+            auto crow_at = [&](const int n) { return reinterpret_cast<half_t*>(reinterpret_cast<char*>(Cb) + (cbyte + 2u * (unsigned)n)); };
+            auto rrow_at = [&](const int n) { return reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(Rb) + (rbyte + 2u * (unsigned)n)); };
+            auto rv_at = [&](const int n) { return reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(p.rowvec) + (vbyte + 2u * (unsigned)n)); };
             // LayerNorm folded into the GEMM: out = rs * acc + rt * c1[n] (then bias / row vector / residual as usual)
             const float* cvp = p.rowscale ? p.colvec : nullptr;
             const float rs = cvp ? p.rowscale[2 * (unsigned)m] : 1.f, rt = cvp ? p.rowscale[2 * (unsigned)m + 1] : 0.f;
@@ -634,14 +641,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             const vsx_f2 g01 = gelu_erf_f2(vsx_f2{gv[0], gv[1]}), g23 = gelu_erf_f2(vsx_f2{gv[2], gv[3]});
                             float o[4] = {hv[0] * g01[0], hv[1] * g01[1], hv[2] * g23[0], hv[3] * g23[1]};
                             if (rrow) {
-                                const h4 b = *reinterpret_cast<const h4*>(rrow + nb);
+                                const h4 b = *reinterpret_cast<const h4*>(rrow_at(nb));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                             }
                             h4 pk;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) pk[e] = (half_t)o[e];
-                            *reinterpret_cast<h4*>(crow + nb) = pk;
+                            *reinterpret_cast<h4*>(crow_at(nb)) = pk;
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -650,8 +657,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                                     const float bh = p.bias ? (float)p.bias[n] : 0.f;
                                     const float bg = p.bias ? (float)p.bias[Ni + n] : 0.f;
                                     float o = (hv[e] + bh) * gelu_erf_f(gv[e] + bg);
-                                    if (rrow) o += (float)rrow[n];
-                                    crow[n] = (half_t)o;
+                                    if (rrow) o += (float)*rrow_at(n);
+                                    *crow_at(n) = (half_t)o;
                                 }
                             }
                         }
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                                 lo2 = __builtin_bit_cast(uint2, rpre[PRE_RES ? (i * TN + j) * 4 + 2 * a : 0]);
                                 hi2 = __builtin_bit_cast(uint2, rpre[PRE_RES ? (i * TN + j) * 4 + 2 * a + 1 : 0]);
                             } else {
-                                const uint4 v = *reinterpret_cast<const uint4*>(rrow + nb0 + wc * WN + j * 32 + 16 * a + 8 * hi);
+                                const uint4 v = *reinterpret_cast<const uint4*>(rrow_at(nb0 + wc * WN + j * 32 + 16 * a + 8 * hi));
                                 lo2 = make_uint2(v.x, v.y);
                                 hi2 = make_uint2(v.z, v.w);
                             }
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }
                         if (rv) {
-                            const h4 b = *reinterpret_cast<const h4*>(rv + nb);
+                            const h4 b = *reinterpret_cast<const h4*>(rv_at(nb));
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             h4 b;
                             if (p.rvec8) b = rq[g];
                             else if (PRE_RES && r_loaded) b = rpre[PRE_RES ? (i * TN + j) * 4 + g : 0];
-                            else b = *reinterpret_cast<const h4*>(rrow + nb);
+                            else b = *reinterpret_cast<const h4*>(rrow_at(nb));
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                         const auto s1 = __builtin_amdgcn_permlane32_swap(pkw[2 * a][1], pkw[2 * a + 1][1], false, false);
                         const uint4 out = make_uint4(s0[0], s1[0], s0[1], s1[1]);
                         const int nc = nb0 + wc * WN + j * 32 + 16 * a + 8 * hi;
-                        *reinterpret_cast<uint4*>(crow + nc) = out;
+                        *reinterpret_cast<uint4*>(crow_at(nc)) = out;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     continue;
@@ -757,21 +764,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }
                         if (rv) {
-                            const h4 b = *reinterpret_cast<const h4*>(rv + nb);
+                            const h4 b = *reinterpret_cast<const h4*>(rv_at(nb));
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }
                         if (rrow) {
                             h4 b;
                             if (PRE_RES && r_loaded) b = rpre[PRE_RES ? (i * TN + j) * 4 + g : 0];
-                            else b = *reinterpret_cast<const h4*>(rrow + nb);
+                            else b = *reinterpret_cast<const h4*>(rrow_at(nb));
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] += (float)b[e];
                         }
                         h4 pk;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) pk[e] = (half_t)o[e];
-                        *reinterpret_cast<h4*>(crow + nb) = pk;
+                        *reinterpret_cast<h4*>(crow_at(nb)) = pk;
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -779,9 +786,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_kernel(const GemmP
                             if (n < Ni) {
                                 float v = o[e];
                                 if (p.bias) v += (float)p.bias[n];
-                                if (rv) v += (float)rv[n];
-                                if (rrow) v += (float)rrow[n];
-                                crow[n] = (half_t)v;
+                                if (rv) v += (float)*rv_at(n);
+                                if (rrow) v += (float)*rrow_at(n);
+                                *crow_at(n) = (half_t)v;
                             }
                         }
                     }

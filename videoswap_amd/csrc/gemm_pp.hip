@@ -50,6 +50,15 @@ namespace {
 typedef const __attribute__((address_space(4))) GemmParams* kparams_t;
 typedef float f2v __attribute__((ext_vector_type(2)));
 
+// The lane id from the execution mask instead of from a register that would have to stay live: v_mbcnt_lo / _hi count the
+// lanes below this one (all lanes are active wherever this is called).  `volatile`: never hoisted, never merged with an
+// earlier copy — which is the point (see epilogue_pp).  tools/cpu_check strips asm statements: there the hint passes through.
+__device__ __forceinline__ int fresh_lane(const int lane_hint) {
+    int l = lane_hint;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 __device__ __forceinline__ kparams_t kernarg_params() {
     kparams_t kp = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();   // GemmParams is the first kernel argument
     asm volatile("" : "+s"(kp));                 // opaque: fields are (re)loaded where they are used
@@ -300,7 +309,14 @@ __device__ __forceinline__ void epilogue_vt(f16v (&acc)[5][2], float* stg, const
 
 template <int TM, int EPI, int PD, bool SUBPIX = false>
 __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, const int mrow0, const int ncol0,
-                                            const int gcol0, const int lane) {
+                                            const int gcol0, const int lane_in) {
+    // Everything the epilogue derives from the lane id (4 * lane, 16 * lane, column octets ...) is loop-invariant over the
+    // tile loop: the compiler hoists it in front of the K loop, runs out of registers there and SPILLS it — and the reload
+    // in here is a VMEM load whose wait (vmcnt(0)) also waits for the addend ring (round 5's code objects: 1 - 5 such
+    // values in the kinds with an addend; videoswap_amd/build.py refuses a library whose hand-scheduled kernels touch
+    // scratch).  A lane id recomputed per tile (fresh_lane) keeps those values local to the epilogue: a handful of VALU operations
+    // per tile, and not even the lane id itself has to survive the K loop.
+    const int lane = fresh_lane(lane_in);
     constexpr bool ADD = (EPI & EPI_ADD) != 0, LN = (EPI & EPI_LN) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
     constexpr bool STATS = (EPI & EPI_STATS) != 0;
     static_assert(!STATS || (!LN && !GEGLU), "row statistics come from the plain / addend epilogues");
@@ -506,8 +522,11 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p->B), 0, (int)p->b_bytes, 0x00020000);
     // second conv source (skip concat): built here, not where it is used — an s_load in a load phase would put an
     // lgkmcnt(0) (and with it the fragment ds_reads) in front of the DMA issue
-    const __amdgpu_buffer_rsrc_t rsrcA2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<half_t*>(CONV && p->A2 ? p->A2 : p->A), 0, (int)(CONV ? p->a2_bytes : 0u), 0x00020000);
+    // (the sub-pixel form, CONV = 3, is single-source by contract — gemm.hip checks C2 == 0 — and carries no third descriptor:
+    // its four extra SGPRs were spilled as a 16-byte stack object, the only private segment of that kernel)
+    __amdgpu_buffer_rsrc_t rsrcA2 = rsrcA;
+    if constexpr (CONV == 1 || CONV == 2)
+        rsrcA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p->A2 ? p->A2 : p->A), 0, (int)p->a2_bytes, 0x00020000);
 
     const int Mi = (int)p->M;
     const int tiles_n = p->tiles_n;
@@ -531,7 +550,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     const int w5 = wave * GB + (rot_on && !CONV ? 2 * (((int)(blockIdx.x >> 3) * 7) % 20) : 0);       // this wave's first B piece
     const int wa = wave * GA + (rot_on ? 2 * (((int)(blockIdx.x >> 3) * 5) % (BM / 16)) : 0);         // ... and A piece
     auto a_piece = [&](const int q) { return wa + q < BM / 8 ? wa + q : wa + q - BM / 8; };
-    const int Ngeglu = (int)p->N;
+    const int Ngeglu = geglu ? (int)p->N : 0;    // (only the GEGLU row interleave needs it: M and N are neighbours in the kernarg
+                                                 // segment, and a merged 16-byte load keeps four SGPRs alive for two values)
 
     // per-lane parts of the operand offsets (bytes): row-in-piece * pitch + swizzled k slot
     const int vb_e = (int)((unsigned)lrow * ldb2) + kofs_e * 2;
@@ -593,9 +613,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             i_rowB += (unsigned)(cls * (int)p->N) * ldb2;
         }
         if constexpr (CONV) {
-            const unsigned Wo = (unsigned)p->Wo, hw = (unsigned)p->Ho * Wo;
-            const int stride = p->stride, pad = p->pad, ks = p->ks, ups = p->ups;
+            // CONV = 2 (shared A slab) and 3 (sub-pixel form) are stride-1 3x3 windows with one zero row / column around a
+            // source that is not upsampled, output size = input size (launch_pp / gemm.hip route nothing else here): constants,
+            // not launch parameters — fewer scalars alive across the K loop (the kernels spill 40 - 70 SGPRs into VGPR lanes)
+            constexpr bool fixed = CONV >= 2;
             const int H = p->H, W = p->W;
+            const unsigned Wo = fixed ? (unsigned)W : (unsigned)p->Wo, hw = (fixed ? (unsigned)H : (unsigned)p->Ho) * Wo;
+            const int stride = fixed ? 1 : p->stride, pad = fixed ? 1 : p->pad, ks = fixed ? 3 : p->ks, ups = fixed ? 0 : p->ups;
             const int Hs = ups ? (H >> 1) : H, Ws = ups ? (W >> 1) : W;
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
@@ -632,7 +656,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
         }
         const int kt = i_kt;
         if constexpr (CONV) {
-            const int C1 = p->C1, C2 = p->C2, ks = p->ks;
+            const int C1 = p->C1, C2 = CONV == 3 ? 0 : p->C2, ks = CONV >= 2 ? 3 : p->ks;
             const int csz = t_second ? C2 : C1;
             if (t_src_dirty) {                  // first slab of a source: the pixel offsets in that source's channel count
 #pragma unroll
@@ -642,7 +666,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             i_hasA = !ashift || t_kw == 0;
             if (i_hasA) i_aslot ^= 1;
             if (t_dirty) {                      // first slab of a tap (a slab never straddles a tap or the two sources)
-                const int ups = p->ups;
+                const int ups = CONV >= 2 ? 0 : p->ups;
                 const int Ws = ups ? (p->W >> 1) : p->W;
                 const int kw_e = ashift ? 1 : t_kw;         // shared A slab: the window of the centre column
                 t_bit = 3 * t_kh + kw_e;
@@ -708,7 +732,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
                                        : ((mk & 512) ? t_ro : t_re) + ((mk & 1024) ? t_co : t_ce);
                 const bool in = ((mk >> t_bit) & 1) != 0 && !(i_tail && kofs >= ktail_from);
                 const int v = in ? a_vb[q < GA ? q : 0] + dlt : OOB_OFF;
-                if (i_second) {
+                if (CONV != 3 && i_second) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, dst, 16, v, (int)i_soffA, 0, 0);
                 } else {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, dst, 16, v, (int)i_soffA, 0, 0);
@@ -752,6 +776,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
     int aoff[ashift ? TM : 1];
     int c_kw = 0, c_aslot = 0;
     auto shared_a_setup = [&]() {
+        const int ln = fresh_lane(lane);                         // (per slab: the pieces of `base` must not be hoisted and spilled)
+        const int l31 = ln & 31, hi = ln >> 5;
         const int r = l31 + c_kw - 1;                            // -1 .. 32: the rows of an edge lane are never read
         const int base = c_aslot * STAGE + (wr * WM + r) * 128 + ((hi ^ ((r >> 1) & 7)) * 16);
 #pragma unroll
@@ -766,7 +792,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p_unused,
             aoff[i] = edge ? ZERO_OFF : base + i * 4096;
         }
     };
-    auto ldfrag = [&](const int slot_off, const int ks) {
+    auto ldfrag = [&](const int slot_off, const int ks_) {
+        // ks * 32 through an opaque scalar: `a_addr ^ (ks * 32)` is loop-invariant for ks = 1, 2, 3, and the compiler keeps all six
+        // pre-XORed fragment addresses in registers across the whole kernel otherwise (six VGPRs the epilogues with an addend ring
+        // do not have: they spilled).  One v_xor per fragment address and k-step instead.
+        int ks = ks_;
+        asm volatile("" : "+s"(ks));
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if constexpr (ashift) af[i] = *reinterpret_cast<const h8*>(smem + (aoff[i] ^ (ks * 32)));
