@@ -229,6 +229,40 @@ def test_persistent_linear(M, N, K, res, sched):
         assert torch.equal(old, new), 'persistent and tile kernels must agree bit for bit'
 
 
+@pytest.mark.parametrize('tune', [1, 2, 2 + 16])
+def test_tile_kernels_late_residual_prefetch_at_every_loop_length(tune):
+    """ADVICE r5 (gemm.hip, RES_LATE): the NRES residual loads of the workgroup-per-tile kernels go out behind the last piece of
+    the last slab, and every slab wait after that point counts `vmcnt(later * G + NRES)` — correct only if every wave issues exactly
+    NRES loads and the issue iteration is kt_r = max(nloc - 1 - PREFETCH, 0).  The host model (tools/cpu_check, case 22) checks the
+    counts with late-landing DMA; this is the same on hardware, for every K-loop length around the ring depth — nloc = 1 ... PREFETCH
+    + 4 slabs, i.e. including nloc = PREFETCH + 2 where the last slab's pieces sit right inside the allowed-in-flight window — on
+    the 8-wave 128 x 320 tile (tile_tune 1: the late waves issue their pieces one k-step later), the 4-wave 128 x 160 tile with two
+    ring slots (2) and with four (2 + 16), with ragged M (rows past M are clamped, not skipped: NRES loads per wave).  A slab read
+    before it landed would show against the fp32 reference AND against the early placement (pp_sched bit 64: residual in front of
+    the loop, waits without the exact count), which must agree bit for bit."""
+    o = ops()
+    prefetch = 3 if tune & 16 else 1
+    try:
+        o.set_option('gemm_pp', 0)
+        o.set_option('tile_tune', tune)
+        for nloc in range(1, prefetch + 5):
+            K = 64 * nloc
+            for M in (4096, 4000):
+                x, w, b = rnd(M, K, seed=700 + nloc), rnd(1280, K, seed=701 + nloc, scale=K ** -0.5), rnd(1280, seed=702)
+                r = rnd(M, 1280, seed=703 + nloc)
+                ref = x.float() @ w.float().t() + b.float() + r.float()
+                o.set_option('pp_sched', 0)
+                late = [o.linear(x, w, b, residual=r) for _ in range(3)]
+                o.set_option('pp_sched', 64)
+                early = o.linear(x, w, b, residual=r)
+                assert rel_err(late[0], ref) < 2e-3, (tune, nloc, M)
+                assert all(torch.equal(t, early) for t in late), (tune, nloc, M)
+    finally:
+        o.set_option('gemm_pp', 1)
+        o.set_option('tile_tune', 0)
+        o.set_option('pp_sched', 0)
+
+
 @pytest.mark.parametrize('ln', [False, True])
 @pytest.mark.parametrize('rows,nimg,N,K', [(4096, 16, 320, 320), (1024, 64, 640, 640), (256, 256, 1280, 1280), (4096, 128, 320, 320)])
 def test_persistent_transposed_store(rows, nimg, N, K, ln):

@@ -88,23 +88,23 @@ def test_shared_cfg_prefix_equals_the_duplicated_batch(setup):
 
 
 def test_shared_cfg_prefix_of_several_clips(setup):
-    """Several clips denoised together (bench.py's default: four per step): `VideoSwapPipeline.__call__` tags its own
-    `torch.cat([latents] * 2)` as two equal halves; the UNet then runs conv_in, the first resnet and the first self-attention on
-    ONE half.  Must match the untagged batch (same arithmetic per element), keep the clips apart, and an untagged batch whose
-    halves merely happen to be equal must not be shared."""
+    """Several clips denoised together (bench.py's throughput leg: four per step): `VideoSwapPipeline.__call__` passes
+    `cfg_halves_equal=True` with its own `torch.cat([latents] * 2)` (an explicit keyword, ADVICE r5: an attribute on the tensor
+    is dropped by any op in between); the UNet then runs conv_in, the first resnet and the first self-attention on ONE half.
+    Must match the unstated batch (same arithmetic per element), keep the clips apart, and a batch whose halves merely happen
+    to be equal must not be shared unless the caller says so."""
     blob, ora, prod = setup
     case = blob['cases']['cfg_adapter_T3_16x24']
     x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
     clips = torch.cat([x[:1], x[1:2] * 0.5 + 0.1])                    # two different clips
     text4 = torch.cat([txt[:1], txt[:1] * 0.7, txt[1:2], txt[1:2] * 0.7])     # [uncond clip 0, 1 ; cond clip 0, 1]
     plain = torch.cat([clips, clips])
-    tagged = torch.cat([clips, clips])
-    tagged.vsx_cfg_halves_equal = True
     one_row = torch.zeros(1, 8)
-    assert prod._shared_cfg_prefix(tagged, text4, one_row) == 2 and prod._shared_cfg_prefix(plain, text4, one_row) == 0
-    assert prod._shared_cfg_prefix(tagged, text4[:2], one_row) == 0       # text rows must cover the whole batch
+    assert prod._shared_cfg_prefix(plain, text4, one_row, True) == 2 and prod._shared_cfg_prefix(plain, text4, one_row) == 0
+    assert prod._shared_cfg_prefix(plain, text4[:2], one_row, True) == 0       # text rows must cover the whole batch
+    assert prod.vsx_cfg_keyword        # what VideoSwapPipeline asks before it passes the keyword to a UNet object
     with torch.no_grad():
-        a = prod(tagged, 481, text4).sample.float().cpu()
+        a = prod(plain.clone(), 481, text4, cfg_halves_equal=True).sample.float().cpu()      # (survives a clone: no tensor attribute)
         b = prod(plain, 481, text4).sample.float().cpu()
     sync()
     assert a.shape == b.shape and torch.isfinite(a).all()
@@ -262,6 +262,35 @@ def test_hip_graph_replay_is_bit_identical_to_eager(setup):
             assert not torch.equal(changed, eager[0])
             prod.load_state_dict(sd)
             assert torch.equal(prod(x, 21, txt).sample, eager[0])
+        finally:
+            prod.enable_hip_graphs(False)
+
+
+@pytest.mark.gpu
+def test_hip_graph_replay_keeps_the_shared_cfg_prefix_and_keys_on_it(setup):
+    """the graph cache cloned the sample into its static buffer, which drops a stride-0 batch view — the shared CFG
+    prefix was silently never taken under replay — and its key ignored the proof.  `forward` now decides `half` on the caller's
+    tensor and hands it to the cache: (i) a stride-0 CFG batch replays the SHARED body (bit-identical to the eager shared
+    forward), (ii) the materialised batch of the same shape gets its OWN graph (two captures), bit-identical to its eager
+    forward — a graph captured with sharing is never replayed for a batch whose halves may differ."""
+    blob, ora, prod = setup
+    case = blob['cases']['cfg_adapter_T3_16x24']
+    x, txt = case['sample'].half().to(DEV), case['text'].half().to(DEV)
+    one = x[:1].contiguous()
+    dup = one.expand(2, *one.shape[1:])
+    differ = torch.cat([one, one * 0.5 + 0.25])             # same shape, halves NOT equal
+    with torch.no_grad():
+        eager_shared = prod(dup, 481, txt).sample
+        eager_differ = prod(differ, 481, txt).sample
+        assert not torch.equal(eager_shared[1], eager_differ[1])
+        prod.enable_hip_graphs(True)
+        try:
+            for _ in range(2):
+                assert torch.equal(prod(dup, 481, txt).sample, eager_shared)
+                assert torch.equal(prod(differ, 481, txt).sample, eager_differ)
+            assert prod._graphs.captures == 2 and prod._graphs.replays == 4
+            halves = sorted(k[3] for k in prod._graphs.entries)
+            assert halves == [0, 1], halves
         finally:
             prod.enable_hip_graphs(False)
 

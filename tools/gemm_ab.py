@@ -159,7 +159,7 @@ def main():
     if args.auto_scheds:        # the product's own dispatch (gemm_pp = 1) under different pp_sched bits; 'tile' stays the baseline column
         variants = [('tile', 0, 0)] + [(f'auto/s{int(n)}', 1, int(n)) for n in args.auto_scheds.split(',')]
     if args.libs:               # two BUILDS of the library, both under the product's dispatch; the first is the baseline column
-        names = args.libs.split(',')
+        names = args.libs.replace('+', ',').split(',')
         for n in names:
             _LIBS[n] = load_build(n)
         variants = [(n, 1, 0) for n in names]

@@ -29,23 +29,25 @@ class GraphCache:
         self.captures = 0
         self.on_eager = None          # optional callable(bool): bench.py switches its launch profiler with it
 
-    def _key(self, unet, sample, text, residuals):
+    def _key(self, unet, sample, text, residuals, half):
         from .attention import Attention
         res = None if residuals is None else tuple(tuple(r.shape) for r in residuals)
-        return (tuple(sample.shape), tuple(text.shape), res, sample.dtype, str(sample.device), unet._weights_epoch,
+        # `half` (the shared CFG prefix, decided by AnimateDiffUNet3DModel.forward on the caller's tensor) is part of the
+        # signature: a graph captured with the prefix shared must never be replayed for a batch whose halves differ
+        return (tuple(sample.shape), tuple(text.shape), res, int(half), sample.dtype, str(sample.device), unet._weights_epoch,
                 Attention.processor_epoch)
 
-    def run(self, unet, sample, silu_emb, text, residuals):
+    def run(self, unet, sample, silu_emb, text, residuals, half=0):
         self.calls += 1
         if self.eager_every and self.calls % self.eager_every == 0:
             if self.on_eager:
                 self.on_eager(True)
             try:
-                return unet._forward_body(sample, silu_emb, text, residuals)
+                return unet._forward_body(sample, silu_emb, text, residuals, half)
             finally:
                 if self.on_eager:
                     self.on_eager(False)
-        key = self._key(unet, sample, text, residuals)
+        key = self._key(unet, sample, text, residuals, half)
         e = self.entries.get(key)
         if e is None:
             stale = [k for k in self.entries if k[-2:] != key[-2:]]      # other weights / processors: dead graphs
@@ -53,7 +55,7 @@ class GraphCache:
                 del self.entries[k]
             if len(self.entries) >= self.max_entries:
                 self.entries.clear()
-            e = self.entries[key] = self._capture(unet, sample, silu_emb, text, residuals)
+            e = self.entries[key] = self._capture(unet, sample, silu_emb, text, residuals, half)
         e.sample.copy_(sample)
         e.semb.copy_(silu_emb)
         if e.text.data_ptr() != text.data_ptr():
@@ -69,7 +71,7 @@ class GraphCache:
             ops.FlopCounter.gemm_saved += e.flop_gemm_saved
         return e.out.clone()
 
-    def _capture(self, unet, sample, silu_emb, text, residuals):
+    def _capture(self, unet, sample, silu_emb, text, residuals, half=0):
         e = _Entry()
         e.keep = None
         e.sample, e.semb, e.text = sample.clone(), silu_emb.clone(), text.clone()
@@ -85,7 +87,7 @@ class GraphCache:
         StepInvariantCache.bypass = True
         try:
             with torch.cuda.stream(side):
-                unet._forward_body(e.sample, e.semb, e.text, e.residuals)
+                unet._forward_body(e.sample, e.semb, e.text, e.residuals, half)
         except BaseException:
             StepInvariantCache.bypass = False
             raise
@@ -98,7 +100,7 @@ class GraphCache:
         try:
             e.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(e.graph):
-                e.out = unet._forward_body(e.sample, e.semb, e.text, e.residuals)
+                e.out = unet._forward_body(e.sample, e.semb, e.text, e.residuals, half)
             # the graph's kernel arguments point at the folded LayerNorm operands of ops._fold_cache: hold them
             e.keep = ops.fold_cache_tensors()
         finally:

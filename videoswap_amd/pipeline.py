@@ -284,18 +284,20 @@ class VideoSwapPipeline:
             # the UNet then knows the halves are identical up to the first cross-attention and computes that prefix once
             if do_cfg and latents.shape[0] == 1:
                 model_input = latents.expand(2, *latents.shape[1:])
-            elif do_cfg:        # several clips denoised together: [uncond clips ; cond clips], tagged as two equal halves
+            elif do_cfg:        # several clips denoised together: [uncond clips ; cond clips], two equal halves (stated below)
                 model_input = torch.cat([latents] * 2)
-                model_input.vsx_cfg_halves_equal = True
             else:
                 model_input = latents
             if adapter_state is not None and n * t2i_start <= i <= n * t2i_end:
                 t2i_residual = list(adapter_state)      # fresh list: the UNet pops from it
             else:
                 t2i_residual = None
+            # (an explicit keyword, not an attribute on the tensor: any op in between would drop the latter silently, ADVICE r5;
+            # only this package's UNet knows the keyword — a foreign UNet object is called with the reference's own signature)
+            extra = {'cfg_halves_equal': True} if do_cfg and latents.shape[0] > 1 and getattr(self.unet, 'vsx_cfg_keyword', False) else {}
             noise_pred = self.unet(model_input, t, encoder_hidden_states=prompt_embeds,
                                    cross_attention_kwargs=cross_attention_kwargs,
-                                   down_block_additional_residuals=t2i_residual, return_dict=False)[0]
+                                   down_block_additional_residuals=t2i_residual, return_dict=False, **extra)[0]
             a_t, a_n = self.scheduler.coefficients(t)
             if do_cfg:
                 latents = ops.cfg_ddim_step(latents, noise_pred[:batch_size], noise_pred[batch_size:], guidance_scale,

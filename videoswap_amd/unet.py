@@ -612,14 +612,18 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         self._temb_cache = {}
         self._semb_cache = {}
         self._graphs = None           # graphs.GraphCache when HIP-graph replay is enabled
+        self.vsx_cfg_keyword = True   # forward() accepts cfg_halves_equal (VideoSwapPipeline asks before passing it)
         self._weights_epoch = getattr(self, '_weights_epoch', 0)
 
     # ---------------------------------------------------------------------------------------------
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
-                cross_attention_kwargs=None, down_block_additional_residuals=None, return_dict=True):
+                cross_attention_kwargs=None, down_block_additional_residuals=None, return_dict=True, cfg_halves_equal=False):
         """sample [B, C, F, H, W] fp16 on the GPU; timestep scalar / 0-dim / [B] tensor; encoder_hidden_states
         [B, 77, D] or [B, 16, 77, D]; down_block_additional_residuals: list the UNet pops from (unet.py:422,435),
-        entries [(B F), C, h, w] (reference layout) or channels-last [(B F), h, w, C] tagged `.vsx_nhwc`."""
+        entries [(B F), C, h, w] (reference layout) or channels-last [(B F), h, w, C] tagged `.vsx_nhwc`.
+        cfg_halves_equal (an extension of the reference signature): the caller's statement that
+        sample[:B/2] and sample[B/2:] hold the same values (classifier-free guidance, pipeline_videoswap.py:556) — the UNet then
+        computes everything in front of the first cross-attention once.  A stride-0 batch view proves the same by itself."""
         if attention_mask is not None or class_labels is not None:
             raise NotImplementedError('attention_mask / class_labels are never used on the VideoSwap path')
         if sample.dim() != 5:
@@ -641,18 +645,22 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
             # the caller's list is consumed (unet.py:422,435); layout conversion happens outside the captured body
             taken = [residuals.pop(0) for _ in range(len(residuals))]
             residuals = [r if getattr(r, 'vsx_nhwc', False) else r.permute(0, 2, 3, 1).contiguous() for r in taken]
+        # decided HERE, on the caller's tensor and the caller's statement: a clone (graphs.py's static buffers) or any other op in
+        # between would lose a stride-0 view, and nothing downstream re-derives it
+        half = self._shared_cfg_prefix(sample, encoder_hidden_states, silu_emb, bool(cfg_halves_equal))
         if self._graphs is not None and self._graphable(sample, silu_emb, encoder_hidden_states):
-            out = self._graphs.run(self, sample, silu_emb, encoder_hidden_states, residuals)
+            out = self._graphs.run(self, sample, silu_emb, encoder_hidden_states, residuals, half)
         else:
-            out = self._forward_body(sample, silu_emb, encoder_hidden_states, residuals)
+            out = self._forward_body(sample, silu_emb, encoder_hidden_states, residuals, half)
         if not return_dict:
             return (out,)
         return UNet3DConditionOutput(sample=out)
 
-    def _forward_body(self, sample, silu_emb, encoder_hidden_states, residuals):
+    def _forward_body(self, sample, silu_emb, encoder_hidden_states, residuals, half=0):
         """Everything between the time embedding and the output tensor: kernel launches on the current stream and
         device allocations only (no host synchronisation, no host-side data dependence), so that it can be captured
-        into a HIP graph (`enable_hip_graphs`).  `residuals`: channels-last adapter maps or None."""
+        into a HIP graph (`enable_hip_graphs`).  `residuals`: channels-last adapter maps or None.  `half` > 0: the batch is
+        two equal CFG halves of `half` items (`_shared_cfg_prefix`, decided by `forward`): the prefix runs on one of them."""
         B, _, F, H, W = sample.shape
         shard = self._frame_shard
         geo = Geometry(B, F, None if shard is None else shard.gn_hook, None if shard is None else shard.total_frames,
@@ -663,7 +671,6 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         # stride-0 batch view (`latents.expand(2, ...)`: VideoSwapPipeline does), conv_in, the first resnet and the first
         # self-attention (N = H*W keys: the largest attention launch of the model) run once for both halves.
         shared_geo = None
-        half = self._shared_cfg_prefix(sample, encoder_hidden_states, silu_emb)
         if half:
             shared_geo = Geometry(half, F)
             x = ops.pack_latents(sample[:half].contiguous(), 8)
@@ -732,17 +739,17 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         self._weights_epoch = getattr(self, '_weights_epoch', 0) + 1
         return super()._apply(fn, *args, **kwargs)
 
-    def _shared_cfg_prefix(self, sample, text, silu_emb):
+    def _shared_cfg_prefix(self, sample, text, silu_emb, stated=False):
         """Can the two CFG halves of the batch share everything in front of the first cross-attention?  -> the number of batch
         items of ONE half (0: no).  Only when the caller PROVES that the halves are identical — a stride-0 batch dimension
-        (`latents.expand(2, ...)`: one clip), or, for several clips denoised together, the tag `vsx_cfg_halves_equal` that
-        `VideoSwapPipeline.__call__` puts on its own `torch.cat([latents] * 2)` — AND they share the timestep (one time-
+        (`latents.expand(2, ...)`: one clip), or, for several clips denoised together, the keyword `cfg_halves_equal=True` that
+        `VideoSwapPipeline.__call__` passes with its own `torch.cat([latents] * 2)` (`stated`) — AND they share the timestep (one time-
         embedding row: a [B] timestep tensor gives B rows, and the shared prefix would hand the first half's rows to both), the
         first block is a cross-attention block whose first self- and cross-attention run on this package's plain fused
         processors (a Prompt-to-Prompt controller hooked there is `vsx_native` too, but it expects both halves of the batch:
         below 32 x 32 latents it is called on that very layer), and the clip is not frame-sharded."""
         nb = sample.shape[0]
-        proven = (nb == 2 and sample.stride(0) == 0) or (nb % 2 == 0 and getattr(sample, 'vsx_cfg_halves_equal', False))
+        proven = (nb == 2 and sample.stride(0) == 0) or (nb % 2 == 0 and stated)
         if not proven or self._frame_shard is not None:
             return 0
         if silu_emb.shape[0] != 1:
