@@ -9,6 +9,7 @@
 #   timing         tools/gemm_timing.py        phase stamps of the tile kernels on the small-M shapes (timing build)
 #   ab:<args>      tools/gemm_ab.py <args>     free-form A/B ("," for spaces)
 #   py:<args>      python <args>               any tool ("," for spaces)
+#   hip:<name>     hipcc tools/ubench/<name>.hip && run it
 #   kernels        pytest tests/test_kernels_gpu.py
 #   pytest         the whole -m gpu suite
 #   bench          python bench.py             (default line, both baseline legs)
@@ -60,6 +61,9 @@ for STEP in "$@"; do
     py:*)
       A=${STEP#py:}; N=$(echo "$A" | md5sum | cut -c1-6)
       timeout 900 python ${A//,/ } > $O/${TAG}_py_$N.txt 2>&1; echo "# python ${A//,/ }"; show py_$N 70 ;;
+    hip:*)                    # hip:NAME — compile tools/ubench/NAME.hip for gfx950 on the box and run it
+      A=${STEP#hip:}
+      ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o /tmp/$A tools/ubench/$A.hip && timeout 300 /tmp/$A ) > $O/${TAG}_hip_$A.txt 2>&1; show hip_$A 40 ;;
     kernels)
       ( time timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -rf ) > $O/${TAG}_kernels.txt 2>&1; show kernels 15 ;;
     pytest)

@@ -408,9 +408,9 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
                         const int co = j * 16 + 8 * q + 4 * hi;         // column offset inside the wave's 80 outputs
                         float hv[4], gv[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            hv[e] = acc[j][i][4 * q + e] * alpha;
-                            gv[e] = acc[j][i][8 + 4 * q + e] * alpha;
+                        for (int e = 0; e < 4; ++e) {       // alpha = 1 (pp_supported: a GEGLU launch with another scale stays on the
+                            hv[e] = acc[j][i][4 * q + e];    // tile kernels): x * 1.0f is the identity, 160 packed multiplications per
+                            gv[e] = acc[j][i][8 + 4 * q + e];    // wave and tile fewer in an epilogue that is bound by VALU issue
                         }
                         if constexpr (LN) {
                             const f4v ch = *reinterpret_cast<const f4v*>(cst + 160 + co);
@@ -987,6 +987,7 @@ bool pp_supported(const GemmParams& p) {
     // one prefetched addend: residual or row vector (not both; not under GEGLU); a 32-row block meets <= 2 row vectors
     if (p.rowvec && (p.residual || p.geglu || p.rows_per_vec < 32)) return false;
     if (p.geglu && p.residual) return false;
+    if (p.geglu && p.alpha != 1.f) return false;       // the GEGLU epilogue of the persistent kernel does not multiply by alpha
     if (p.rowscale && p.a_mode == 1) return false;
     if (p.a_mode == 1) {
         const int ctot = p.C1 + p.C2;
