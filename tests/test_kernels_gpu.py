@@ -614,14 +614,48 @@ def test_attention_query_blocks_per_wave(qb, nb, heads, nq, nk, d, kv_div):
     scale = d ** -0.5
     ref, _ = attn_ref(q, k, v, heads, scale, kv_div=kv_div)
     try:
-        ops().set_option('attn_qb', qb)
+        ops().set_option('attn_o16', 0)         # both forms on 32-row O^T tiles (d = 40's default, the 16-row tiles, sums the keys of
+        ops().set_option('attn_qb', qb)         # a block in another order: test_attention_o_tiles_of_16_rows)
         out = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
         ops().set_option('attn_qb', 3 - qb)
         other = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
     finally:
         ops().set_option('attn_qb', 0)
+        ops().set_option('attn_o16', 1)
     assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
     assert torch.equal(out, other), 'a query\'s result must not depend on how many query blocks its wave owns'
+
+
+@pytest.mark.parametrize('nb,heads,nq,nk,kv_div', [(2, 8, 300, 300, 1), (2, 8, 1024, 1001, 1), (4, 8, 1024, 77, 2), (1, 8, 4096, 4096, 1),
+                                                   (2, 5, 96, 333, 1)])
+def test_attention_o_tiles_of_16_rows(nb, heads, nq, nk, kv_div):
+    """d = 40 (round 6): O^T on 16 x 16 x 32 MFMA tiles — 40 channel rows padded to 48 instead of 64, P^T brought into the B-operand
+    layout by v_permlane16_swap, the rescale factors redistributed the same way, the softmax denominator from the ones row 47
+    (csrc/attention.hip, O16; tools/ubench/mfma16_probe.hip probed both instructions).  Against the fp32 reference under the same
+    tolerance as every attention test, and against the 32-row form (option attn_o16 = 0): the two sum a key block's products in
+    another order, so they agree to fp32 rounding of the accumulation, not bit for bit.  Shapes: ragged query tiles, the peeled
+    partial key tile (1001, 333), text keys shared by two batches, the 64 x 64 level's 4096 x 4096, five heads."""
+    d = 40
+    C = heads * d
+    q = rnd(nb, nq, C, seed=231)
+    k, v = rnd(nb // kv_div, nk, C, seed=232), rnd(nb // kv_div, nk, C, seed=233)
+    if nk > 200:
+        k[:, 150] = q[: nb // kv_div, 7] * 3.0          # a late dominant key: the rescale path (alpha through permlane16_swap)
+    scale = d ** -0.5
+    ref, _ = attn_ref(q, k, v, heads, scale, kv_div=kv_div)
+    try:
+        ops().set_option('attn_o16', 1)
+        out = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
+        again = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
+        ops().set_option('attn_o16', 0)
+        old = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
+    finally:
+        ops().set_option('attn_o16', 1)
+    assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < (6e-3 if nq >= 4096 else 4e-3)
+    assert torch.equal(out, again)
+    e_new, e_old = rel_err(out, ref, l2_tol=1.0, row_tol=1.0), rel_err(old, ref, l2_tol=1.0, row_tol=1.0)
+    assert e_new <= 1.1 * e_old + 1e-5, (e_new, e_old)
+    assert float((out.float() - old.float()).norm() / old.float().norm()) < 5e-4
 
 
 @pytest.mark.parametrize('nb,heads,nq,nk,d,kv_div', [(2, 8, 1024, 1024, 40, 1), (2, 8, 1100, 1100, 40, 1), (4, 8, 1024, 77, 40, 2),

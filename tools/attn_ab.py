@@ -40,9 +40,10 @@ def main():
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--vars', default='1,2', help='values of the option (attn_qb: query blocks per wave)')
-    ap.add_argument('--option', default='attn_qb', help='the option to vary (attn_qb)')
+    ap.add_argument('--option', default='attn_qb', help='the option to vary: attn_qb, or attn_o16 (--vars 0,1: 32-row / 16-row O^T tiles at d = 40)')
     args = ap.parse_args()
     variants = [int(v) for v in args.vars.split(',')]
+    tag = {'attn_qb': 'qb', 'attn_o16': 'o16='}.get(args.option, args.option + '=')
     print(f'# flash attention, median of {args.rounds} rounds x {args.reps} launches; us per launch, TFLOP/s of 4*nb*heads*n*n*d')
     for nb, n, heads, d in ((32, 4096, 8, 40), (16, 4096, 8, 40), (32, 1024, 8, 80), (32, 256, 8, 160), (32, 5376, 8, 40)):
         q, k, v, vt = problem(nb, n, heads, d)
@@ -58,7 +59,7 @@ def main():
                 ts[x].append(time_once(fn, args.reps))
         flop = 4.0 * nb * heads * n * n * d
         med = {x: sorted(t)[len(t) // 2] * 1000.0 for x, t in ts.items()}
-        print(f'nb={nb:3d} n={n:5d} d={d:3d}  ' + '  '.join(f'qb{x}: {med[x]:8.1f} us {flop / med[x] / 1e6:7.1f} TF/s' for x in variants),
+        print(f'nb={nb:3d} n={n:5d} d={d:3d}  ' + '  '.join(f'{tag}{x}: {med[x]:8.1f} us {flop / med[x] / 1e6:7.1f} TF/s' for x in variants),
               flush=True)
     # accuracy: every variant against fp32 softmax(QK^T)V on a problem small enough to materialise (incl. a ragged key count)
     for nb, n, heads, d in ((2, 1001, 8, 40), (2, 1024, 8, 80)):
@@ -73,9 +74,10 @@ def main():
         for x in variants:
             ops.set_option(args.option, x)
             o = ops.attention(q, k, vt, heads, d ** -0.5).float()
-            errs.append(f'qb{x}: rel-L2 {float((o - ref).norm() / ref.norm()):.3e} max {float((o - ref).abs().max()):.2e}')
+            errs.append(f'{tag}{x}: rel-L2 {float((o - ref).norm() / ref.norm()):.3e} max {float((o - ref).abs().max()):.2e}')
         print(f'accuracy nb={nb} n={n} d={d}: ' + '  '.join(errs), flush=True)
     ops.set_option('attn_qb', 0)
+    ops.set_option('attn_o16', 1)
 
 
 if __name__ == '__main__':

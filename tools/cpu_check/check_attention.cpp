@@ -12,6 +12,7 @@
 #undef smem                      // (hip_gemm.h maps the GEMM kernels' dynamic LDS; here the arrays are static __shared__)
 
 #include <stdarg.h>
+#include <string.h>
 
 alignas(16) static unsigned char cpuhip_dyn_lds[160 * 1024];
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
@@ -67,9 +68,10 @@ static void report(const char* name, int rc, const std::vector<double>& want, co
 }
 
 // softmax(scale Q K^T) V per (batch, head); K / V batches are shared by kv_div query batches (CFG halves, frames of a clip)
-static long g_attn_var = 0;
+static long g_attn_var = 0, g_attn_o16 = 1;
 namespace vsxg {
-long gemm_option(const char*) { return g_attn_var; }       // the option table lives in gemm.hip: only "attn_qb" is asked here
+// the option table lives in gemm.hip: "attn_qb" (query blocks per wave) and "attn_o16" (16-row O^T tiles at d = 40) are asked here
+long gemm_option(const char* name) { return strcmp(name, "attn_o16") == 0 ? g_attn_o16 : g_attn_var; }
 }
 
 static void run_flash(const char* name, long nb, long kv_div, long heads, long nq, long nk, long d) {
@@ -137,7 +139,12 @@ static void run_temporal(const char* name, long B, long fq, long fk, long hw, lo
 
 int main(int argc, char** argv) {
     const int only = argc > 1 ? atoi(argv[1]) : -1;
-    if (only < 0 || only == 0) run_flash("flash d = 40, 2 heads, 200 x 200 (ragged query and key tiles)", 1, 1, 2, 200, 200, 40);
+    // d = 40 runs on 16-row O^T tiles (16 x 16 x 32 MFMAs, P^T relayout by v_permlane16_swap) unless attn_o16 = 0
+    if (only < 0 || only == 0) run_flash("flash d = 40, 16-row O tiles, 2 heads, 200 x 200 (ragged query and key tiles)", 1, 1, 2, 200, 200, 40);
+    if (only < 0 || only == 15) run_flash("flash d = 40, 16-row O tiles, 2 batches share K/V, 96 x 333 (6 key tiles: rescales)", 2, 2, 1, 96, 333, 40);
+    g_attn_o16 = 0;
+    if (only < 0 || only == 16) run_flash("flash d = 40, 32-row O tiles (attn_o16 = 0), 200 x 200", 1, 1, 2, 200, 200, 40);
+    g_attn_o16 = 1;
     if (only < 0 || only == 1) run_flash("flash d = 80, cross-attention 150 x 77, K/V shared by 2 batches", 2, 2, 2, 150, 77, 80);
     if (only < 0 || only == 2) run_flash("flash d = 160, 64 x 64", 1, 1, 1, 64, 64, 160);
     if (only < 0 || only == 3) run_flash("flash d = 64 (CLIP / VAE head), 130 x 130", 1, 1, 2, 130, 130, 64);

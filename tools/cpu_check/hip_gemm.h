@@ -112,6 +112,46 @@ static inline cpuhip_f16v cpuhip_mfma_32x32x16(cpuhip_h8 a, cpuhip_h8 b, cpuhip_
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) cpuhip_mfma_32x32x16(a, b, c, x, y, z)
+// v_mfma_f32_16x16x32_f16 with the hardware's layout (tools/ubench/mfma16_probe.hip confirmed it on an MI355X): lane l supplies
+// A[l % 16][8 (l / 16) + e] and B[8 (l / 16) + e][l % 16], and owns D[4 (l / 16) + r][l % 16]
+typedef float cpuhip_f4v __attribute__((ext_vector_type(4)));
+static inline cpuhip_f4v cpuhip_mfma_16x16x32(cpuhip_h8 a, cpuhip_h8 b, cpuhip_f4v c, int, int, int) {
+    struct Slot { cpuhip_h8 a, b; };
+    Slot* s = static_cast<Slot*>(cpuhip::ctx.wave_scratch);
+    const int l = (int)(cpuhip::ctx.tid.x & 63);
+    s[l].a = a;
+    s[l].b = b;
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    const int col = l & 15, g = l >> 4;
+    cpuhip_f4v d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = 0.f;
+        for (int k = 0; k < 32; ++k) acc += (float)s[row + 16 * (k >> 3)].a[k & 7] * (float)s[col + 16 * (k >> 3)].b[k & 7];
+        d[r] += acc;
+    }
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) cpuhip_mfma_16x16x32(a, b, c, x, y, z)
+// v_permlane16_swap vdst, src (probed on an MI355X, profiles/r06_gemm_data_power_same_box.txt): the odd 16-lane rows of vdst trade
+// places with the even rows of src — vdst' = {vdst.row0, src.row0, vdst.row2, src.row2}, src' = {vdst.row1, src.row1, vdst.row3,
+// src.row3}; returns (vdst', src')
+typedef unsigned cpuhip_u2v __attribute__((ext_vector_type(2)));
+static inline cpuhip_u2v cpuhip_permlane16_swap(unsigned vdst, unsigned src) {
+    struct Slot { unsigned x, y; };
+    Slot* s = static_cast<Slot*>(cpuhip::ctx.wave_scratch);
+    const int l = (int)(cpuhip::ctx.tid.x & 63);
+    s[l].x = vdst;
+    s[l].y = src;
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    cpuhip_u2v r;
+    if (((l >> 4) & 1) == 0) { r[0] = s[l].x; r[1] = s[l + 16].x; }
+    else { r[0] = s[l - 16].y; r[1] = s[l].y; }
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    return r;
+}
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) cpuhip_permlane16_swap(a, b)
 #define __builtin_amdgcn_s_barrier() (cpuhip::ctx.block_bar->arrive_and_wait())
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

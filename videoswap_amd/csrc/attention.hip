@@ -65,17 +65,36 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //     -> 3.1e-4: dropped.
 // Neither operand delivery nor the VALU instruction count is what bounds this kernel at d = 40: the time is close to
 // (MFMA issue + VALU issue) of a SIMD's waves added up, 29 % of the MFMA work being the 40 -> 48 / 40 -> 64 padding.
-template <int D, int QB = 1>
+// O16 (round 6, d = 40 only): the second product on 16 x 16 x 32 MFMA tiles.  With 32 x 32 tiles O^T pads 40 channel rows to 64
+// (8 MFMAs of 32 cycles per 64-key tile, 37.5 % of them multiplying padding); with 16-row tiles it pads to 48: 2 key blocks x 3
+// row tiles x 2 query tiles = 12 MFMAs of 16 cycles (tools/ubench/mfma16_probe.hip: 17 against 32 ticks per instruction), 192
+// instead of 256 matrix-pipe cycles per key tile of a kernel whose time is MFMA issue + VALU issue added up.  What it takes:
+//   * P^T as the B operand of v_mfma_f32_16x16x32_f16: lane l supplies query column l % 16 and the 8 keys of k-group l / 16.  From
+//     the 32 x 32 C/D layout of S^T (lane = (query q = l & 31, hi = l >> 5); per 32-key block two 8-key chunks s2 = 0 / 1 at keys
+//     16 s2 + 8 hi + 0..7) the four 16-lane rows hold (q 0-15, hi 0), (q 16-31, hi 0), (q 0-15, hi 1), (q 16-31, hi 1):
+//     v_permlane16_swap(X = chunk s2 = 0, Y = chunk s2 = 1) trades X's odd rows for Y's even rows (probed: X' = {X.row0, Y.row0,
+//     X.row2, Y.row2}, Y' = {X.row1, Y.row1, X.row3, Y.row3}), so X' is the whole B operand of queries 0-15 and Y' of queries
+//     16-31, both with k-group g holding keys {0, 16, 8, 24}[g] + 0..7 of the block: four swaps per 32 keys, no LDS round trip;
+//   * the V^T fragment (A operand: lane l supplies channel row l % 16 of the 16-row tile and the same 8 keys): one ds_read_b128 at
+//     key offset {0, 16, 8, 24}[l / 16];
+//   * O^T in the 16 x 16 C/D layout: lane l holds query 16 qt + l % 16 of BOTH query tiles and channels 16 ct + 4 (l / 16) + 0..3,
+//     so the rescale factor of the online softmax (per query, living in the S^T layout's lanes) is redistributed with one more
+//     permlane16_swap(alpha, alpha) -> (alpha of tile 0's queries, alpha of tile 1's), only when a row maximum grew;
+//   * the all-ones row that makes the MFMA produce the softmax denominator sits in row 47 (the last of the 48).
+template <int D, int QB = 1, bool O16 = false>
 __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
+    static_assert(!O16 || (QB == 1 && D % 16 != 0 && D <= 48), "16-row O tiles: one query block per wave, a spare padding row");
     constexpr int DK = (D + 15) / 16;   // k-steps of the QK^T product
     constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T
+    constexpr int CT = (D + 15) / 16;   // 16-row tiles of O^T (O16)
+    constexpr int VROWS = O16 ? CT * 16 : DT * 32;      // rows of the V^T tile in LDS
     constexpr int KSTR = DK * 16 + 8;   // K LDS row (halfs): 2*DK real/zero slots + one dummy slot (odd slot count)
-    constexpr bool HAS_SPARE = (DT * 32 > D);   // a padding row of the O^T tile can carry the softmax denominator
+    constexpr bool HAS_SPARE = (VROWS > D);     // a padding row of the O^T tile can carry the softmax denominator
     constexpr int KSPR = KSTR / 8, VSPR = VSTR / 8;              // 16-byte slots per LDS row
     constexpr int K_UNITS = KV_TILE * KSPR, V_UNITS = D * VSPR;  // 16-byte units per tile (V: rows < D only)
     constexpr int NKI = (K_UNITS + 255) / 256, NVI = (V_UNITS + 255) / 256;   // LDS-DMA instructions per wave
     constexpr int K_BYTES = KV_TILE * KSTR * 2;
-    constexpr int V_BYTES = DT * 32 * VSTR * 2;
+    constexpr int V_BYTES = VROWS * VSTR * 2;
     constexpr int STAGE = K_BYTES + V_BYTES;
     constexpr int OOB_OFF = (int)0x80000000;
 
@@ -143,13 +162,13 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         vv[i] = (u < V_UNITS && slot < 8) ? (int)(((long)row * p.ldvt + slot * 8) * 2) : OOB_OFF;
     }
     // rows >= D of the V^T tiles are never written by the DMA: zero them once, and put the ones row in place
-    for (int i = tid; i < 2 * (DT * 32 - D) * VSTR; i += 256) {
-        const int st = i / ((DT * 32 - D) * VSTR), r = i - st * ((DT * 32 - D) * VSTR);
+    for (int i = tid; i < 2 * (VROWS - D) * VSTR; i += 256) {
+        const int st = i / ((VROWS - D) * VSTR), r = i - st * ((VROWS - D) * VSTR);
         const int row = D + r / VSTR, col = r - (r / VSTR) * VSTR;
         half_t* sv = reinterpret_cast<half_t*>(smem + st * STAGE + K_BYTES);
         // the ones row is the LAST row of the tile: the tail lanes of the final V^T DMA instruction write zeros into
         // the (up to 7) rows right after row D-1, so row D itself is not safe
-        sv[row * VSTR + col] = (HAS_SPARE && row == DT * 32 - 1 && col < KV_TILE) ? (half_t)1.f : (half_t)0.f;
+        sv[row * VSTR + col] = (HAS_SPARE && row == VROWS - 1 && col < KV_TILE) ? (half_t)1.f : (half_t)0.f;
     }
 
     auto issue = [&](int j0, int stage) {
@@ -187,17 +206,22 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
             }
     };
 
-    f16v o[QB][DT];
+    f16v o[QB][O16 ? 1 : DT];
+    f4v o16[O16 ? CT : 1][2];             // O16: [16-row channel tile][16-query tile], 4 registers each
     float m_i[QB], l_i[QB];
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+        for (int t = 0; t < (O16 ? 1 : DT); ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[x][t][r] = 0.f;
         m_i[x] = -INFINITY;
         l_i[x] = 0.f;
     }
+#pragma unroll
+    for (int t = 0; t < (O16 ? CT : 1); ++t)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) o16[t][x] = f4v{0.f, 0.f, 0.f, 0.f};
 
     issue(0, 0);
     int stage = 0;
@@ -257,10 +281,22 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
                 const float alpha = __builtin_amdgcn_exp2f(m_i[x] - m_new);
                 m_i[x] = m_new;
                 if (!HAS_SPARE) l_i[x] *= alpha;
+                if constexpr (O16) {
+                    // alpha belongs to query l & 31; the O^T tiles of this lane hold queries l % 16 (tile 0) and 16 + l % 16 (tile 1)
+                    const auto ab = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, alpha), __builtin_bit_cast(unsigned, alpha), false, false);
+                    // (scalars first: __builtin_bit_cast applied to a vector ELEMENT reads the vector's first element whatever the index)
+                    const unsigned u0 = ab[0], u1 = ab[1];
+                    const float a0 = __builtin_bit_cast(float, u0), a1 = __builtin_bit_cast(float, u1);
 #pragma unroll
-                for (int t = 0; t < DT; ++t)
+                    for (int t = 0; t < CT; ++t)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[x][t][r] *= alpha;
+                        for (int r = 0; r < 4; ++r) { o16[t][0][r] *= a0; o16[t][1][r] *= a1; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < DT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[x][t][r] *= alpha;
+                }
             }
             const float neg_m = -m_i[x];
             float rs = 0.f;
@@ -286,6 +322,31 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         ASTAMP(4);
         // ---- O^T += V^T P^T; a V^T fragment feeds the QB query blocks ----
         // B operand k-slot jj of (kt, s2) on lane hi carries key kt*32 + 16*s2 + 8*hi + jj (K rows are permuted)
+        if constexpr (O16) {
+            const int l15 = lane & 15, g = lane >> 4;
+            const int koff = ((g & 1) << 4) | ((g >> 1) << 3);          // {0, 16, 8, 24}[g]: the key chunk of k-group g after the swaps
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                h8 px, py;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) { px[jj] = (half_t)s[0][kt][jj]; py[jj] = (half_t)s[0][kt][8 + jj]; }
+                u4v ux = __builtin_bit_cast(u4v, px), uy = __builtin_bit_cast(u4v, py);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(ux[w], uy[w], false, false);
+                    ux[w] = sw[0];
+                    uy[w] = sw[1];
+                }
+                const h8 pb0 = __builtin_bit_cast(h8, ux), pb1 = __builtin_bit_cast(h8, uy);      // B operands of queries 0-15 / 16-31
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    const h8 vf = *reinterpret_cast<const h8*>(sV + (t * 16 + l15) * VSTR + kt * 32 + koff);
+                    o16[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb0, o16[t][0], 0, 0, 0);
+                    o16[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb1, o16[t][1], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -320,6 +381,31 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(const AttnParams p) {
         for (int k = 0; k < 6; ++k) o_dbg[k] = t_seg[k];
     }
 #endif
+    if constexpr (O16) {
+        // the denominator sits in row 47 = row 15 of the last 16-row tile: register 3 of the lanes 48 .. 63 (k-group 3), for query
+        // 16 qt + l % 16; lane l stores channels 16 t + 4 (l / 16) + 0..3 of that query
+        const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float den = __shfl(o16[CT - 1][qt][3], 48 + l15, 64);
+            const int q = (q0 - l31) + 16 * qt + l15;       // (q0 - l31: the wave's first query)
+            if (q < p.nq) {
+                const float inv = 1.0f / den;
+                half_t* orow = p.O + b * p.o_bs + (long)q * p.ldo + h * D;
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    const int c = t * 16 + 4 * g;
+                    if (c < D) {
+                        h4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (half_t)(o16[t][qt][e] * inv);
+                        *reinterpret_cast<h4*>(orow + c) = pk;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
         if (HAS_SPARE) {
@@ -369,6 +455,14 @@ int launch_attn(const AttnParams& p, long nb, hipStream_t stream) {
         }
     }
     dim3 grid((unsigned)(((p.nq + 127) / 128) * (long)p.heads * nb));
+    if constexpr (D == 40) {
+        // 16-row O^T tiles (flash_attn_kernel, O16): the inference path of every d = 40 launch; option "attn_o16" / VSX_ATTN_O16 = 0 keeps
+        // the 32-row tiles (A/B runs, equality tests), and the log-sum-exp output of the training step stays on them
+        if (p.lse == nullptr && vsxg::gemm_option("attn_o16") != 0) {
+            hipLaunchKernelGGL((flash_attn_kernel<D, 1, true>), grid, dim3(256), 0, stream, p);
+            return vsx_check_launch("vsx_attention_f16");
+        }
+    }
     hipLaunchKernelGGL((flash_attn_kernel<D, 1>), grid, dim3(256), 0, stream, p);
     return vsx_check_launch("vsx_attention_f16");
 }
