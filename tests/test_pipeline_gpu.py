@@ -100,3 +100,41 @@ def test_foreign_processor_protocol(models):
                 if name in saved:
                     m.set_processor(saved[name])
     assert rel_l2(foreign.float(), base.float()) < 3e-3
+
+
+def test_timestep_work_of_a_loop_is_prepared_in_one_pass(models, monkeypatch):
+    """`AnimateDiffUNet3DModel.prepare_timesteps` (round 6): the sinusoid, the two time-embedding Linears and the 22 per-resnet
+    `time_emb_proj` rows (unet.py:391-397, resnet.py:172-176) of ALL timesteps of a loop in three launches, handed out through
+    the caches the per-step path uses.  The loop must then find every row prepared (no M = 1 projection inside a step), and its
+    result must agree with the per-step path (VSX_PREPARE_TIMESTEPS=0) to the rounding of one GEMM in another tile shape."""
+    from videoswap_amd import ops
+    from videoswap_amd.compat import SD15_SCHEDULER_CONFIG, DDIMScheduler
+    from videoswap_amd.pipeline import VideoSwapPipeline
+    from videoswap_amd.unet import ResnetBlock3D
+    cfg, ora, prod = models
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 4, 4, 16, 16, generator=g).half().to(DEV)
+    txt = torch.randn(1, 77, 64, generator=g).half().to(DEV)
+    pipe = VideoSwapPipeline(unet=prod, scheduler=DDIMScheduler(**SD15_SCHEDULER_CONFIG)).to(DEV)
+    steps = 5
+    monkeypatch.setenv('VSX_PREPARE_TIMESTEPS', '0')
+    prod.clear_step_caches()
+    per_step = pipe.invert(latents=x, prompt_embeds=txt, num_inference_steps=steps).latents.float().cpu()
+    monkeypatch.setenv('VSX_PREPARE_TIMESTEPS', '1')
+    prod.clear_step_caches()
+    calls = []
+    real = ops.linear
+
+    def counting(xin, *a, **k):
+        calls.append(tuple(xin.shape))
+        return real(xin, *a, **k)
+    monkeypatch.setattr(ops, 'linear', counting)
+    prepared = pipe.invert(latents=x, prompt_embeds=txt, num_inference_steps=steps).latents.float().cpu()
+    monkeypatch.setattr(ops, 'linear', real)
+    resnets = [m for m in prod.modules() if isinstance(m, ResnetBlock3D)]
+    assert len(prod._semb_cache) == steps and all(len(r.__dict__['_tproj'].entries) == steps for r in resnets)
+    # the only launches with one row per TIMESTEP are the three of the preparation; no single-row GEMM inside the steps
+    assert sum(1 for s in calls if s[0] == steps and len(s) == 2) == 3, [s for s in calls if len(s) == 2 and s[0] <= steps]
+    assert not any(len(s) == 2 and s[0] == 1 for s in calls), 'a time-embedding row was projected inside a step'
+    assert rel_l2(prepared, per_step) < 2e-3
+    prod.clear_step_caches()

@@ -42,7 +42,7 @@ def main():
     ap.add_argument('--vars', default='1,2', help='values of the option (attn_qb: query blocks per wave)')
     ap.add_argument('--option', default='attn_qb', help='the option to vary: attn_qb, or attn_o16 (--vars 0,1: 32-row / 16-row O^T tiles at d = 40)')
     args = ap.parse_args()
-    variants = [int(v) for v in args.vars.split(',')]
+    variants = [int(v) for v in args.vars.replace('+', ',').split(',')]
     tag = {'attn_qb': 'qb', 'attn_o16': 'o16='}.get(args.option, args.option + '=')
     print(f'# flash attention, median of {args.rounds} rounds x {args.reps} launches; us per launch, TFLOP/s of 4*nb*heads*n*n*d')
     for nb, n, heads, d in ((32, 4096, 8, 40), (16, 4096, 8, 40), (32, 1024, 8, 80), (32, 256, 8, 160), (32, 5376, 8, 40)):

@@ -45,6 +45,12 @@ class StepInvariantCache:
         self.entries[key] = (src, stamp, val)
         return val
 
+    def put(self, src, extra, params, val):
+        """hand in a result computed elsewhere (AnimateDiffUNet3DModel.prepare_timesteps: all timesteps of a loop in one GEMM)"""
+        if len(self.entries) >= self.limit:
+            self.entries.clear()
+        self.entries[(id(src), extra)] = (src, (src._version, param_key(*params)), val)
+
 
 class Linear(nn.Linear):
     """y = x W^T + b on the MFMA GEMM; optional fused residual add.  `row_stats`: a LayerNorm consumes the result — the

@@ -178,6 +178,8 @@ class VideoSwapPipeline:
 
         self.inverse_scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = self.inverse_scheduler.timesteps
+        if hasattr(self.unet, 'prepare_timesteps'):         # the timestep-only work of all steps in three launches
+            self.unet.prepare_timesteps(timesteps, device)
         for i, t in enumerate(timesteps):
             model_input = torch.cat([latents] * 2) if do_cfg else latents
             noise_pred = self.unet(model_input, t, encoder_hidden_states=prompt_embeds).sample
@@ -258,6 +260,8 @@ class VideoSwapPipeline:
 
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = self.scheduler.timesteps
+        if hasattr(self.unet, 'prepare_timesteps'):
+            self.unet.prepare_timesteps(timesteps, device)
         if latents is not None and video_length is None:
             video_length = latents.shape[2]
             height, width = latents.shape[3] * self.vae_scale_factor, latents.shape[4] * self.vae_scale_factor

@@ -793,6 +793,55 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
             return val
         return ops.silu(te(self._timestep_features(timesteps, B, device)))
 
+    def prepare_timesteps(self, timesteps, device=None):
+        """Everything that depends on the timestep alone, for ALL timesteps of a denoising loop in three launches instead of 26
+        per step: the loops (pipeline_videoswap.py:555, :677) call the UNet with 50 scalar timesteps that are known when the
+        scheduler has been set, and per timestep the reference computes the sinusoid, the two time-embedding Linears
+        (unet.py:391-397) and one `time_emb_proj(SiLU(emb))` row per resnet (resnet.py:172-176: 22 of them) — M = 1 GEMMs of
+        13 us each, 0.4 % of a one-clip step pair (profiles/r06_gemm_traffic_by_shape_b1.txt: `gemm M=1 1280->1280`).  Here: one
+        [T, 320] upload, the two Linears at M = T, and ONE GEMM of the [T, 1280] SiLU rows against the concatenated projection
+        weights [sum C_out, 1280]; the rows are then handed out through the same caches the per-step path fills (`_semb_cache`: one
+        tensor OBJECT per timestep value, and on it the per-resnet `_tproj` entries), so the forward itself is unchanged and a
+        timestep that was not prepared is still computed on demand.  Scalar timesteps only; parameters are versioned as
+        everywhere (a LoRA merge / reload recomputes)."""
+        if self._frame_shard is not None or self._graphs is not None or os.environ.get('VSX_PREPARE_TIMESTEPS', '1') == '0':
+            return          # (the environment switch keeps the per-step path for A/B runs)
+        device = device if device is not None else next(self.parameters()).device
+        te = self.time_embedding
+        stamp = param_key(te.linear_1.weight, te.linear_1.bias, te.linear_2.weight, te.linear_2.bias)
+        vals = [float(t) for t in (timesteps.reshape(-1).tolist() if torch.is_tensor(timesteps) else timesteps)]
+        todo = []
+        for v in vals:
+            hit = self._semb_cache.get((v, str(device), self.dtype))
+            if (hit is None or hit[0] != stamp) and v not in todo:
+                todo.append(v)
+        resnets = [m for m in self.modules() if isinstance(m, ResnetBlock3D)]
+        if len(todo) < 2 or not resnets:
+            return
+        tt = torch.tensor(todo, dtype=torch.float64 if any(v != int(v) for v in todo) else torch.int64)
+        feats = self.time_proj(tt).to(device=device, dtype=self.dtype)                  # [T, 320]
+        semb = ops.silu(te(feats))                                                      # [T, 1280]
+        wkey = param_key(*[p for r in resnets for p in (r.time_emb_proj.weight, r.time_emb_proj.bias)])
+        cat = self.__dict__.get('_tproj_cat')
+        if cat is None or cat[0] != wkey:
+            cat = (wkey, torch.cat([r.time_emb_proj.weight.detach() for r in resnets]).contiguous(),
+                   torch.cat([r.time_emb_proj.bias.detach() for r in resnets]).contiguous())
+            self.__dict__['_tproj_cat'] = cat
+        proj = ops.linear(semb, cat[1], cat[2])                                         # [T, sum C_out]
+        if len(self._semb_cache) + len(todo) >= 1024:
+            self._semb_cache.clear()
+        for i, v in enumerate(todo):
+            row = semb[i:i + 1]
+            self._semb_cache[(v, str(device), self.dtype)] = (stamp, row)
+            o = 0
+            for r in resnets:
+                c = r.out_channels
+                cache = r.__dict__.get('_tproj')
+                if cache is None:
+                    cache = r.__dict__['_tproj'] = StepInvariantCache(limit=512)
+                cache.put(row, None, (r.time_emb_proj.weight, r.time_emb_proj.bias), proj[i:i + 1, o:o + c])
+                o += c
+
     def clear_step_caches(self):
         """Drop the step-invariant host caches (time-embedding rows per timestep, per-resnet projections of them,
         text K/V per cross-attention layer).  They are keyed on parameter versions, so this is never needed for
