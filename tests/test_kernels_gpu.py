@@ -478,6 +478,32 @@ def test_group_norm(nimg, rows, C1, C2, groups, silu):
     if silu:
         ref = F.silu(ref)
     assert rel_err(out, ref) < 2e-3
+    # few chunks per image (the per-frame GroupNorms): the apply kernel finalizes the statistics itself (round 6: one launch fewer);
+    # the stand-alone finalize kernel (option gn_fuse = 0) must give the same bits
+    try:
+        ops().set_option('gn_fuse', 0)
+        unfused = ops().group_norm(x, gamma, beta, groups, 1e-5, nimg, silu=silu, x2=x2)
+    finally:
+        ops().set_option('gn_fuse', 1)
+    assert torch.equal(out, unfused)
+
+
+@pytest.mark.parametrize('nimg,rows,C', [(16, 4096, 320), (32, 4096, 320), (64, 1024, 640), (32, 256, 1280), (128, 64, 1280), (1, 65536, 320)])
+def test_group_norm_fused_finalize_at_the_model_shapes(nimg, rows, C):
+    """The GroupNorms in front of `proj_in` (attention.py:61,110; motion_module.py:112,149) at the UNet's real shapes — per frame, 13 - 49
+    chunks per image: statistics finalized inside the apply kernel — and the 5-D GroupNorm of a resnet at B = 1 (771 chunks: the
+    stand-alone finalize kernel stays): against PyTorch, and fused == unfused bit for bit."""
+    x = rnd(nimg, rows, C, seed=320) * 1.5 + 0.3
+    gamma, beta = rnd(C, seed=321) + 1.0, rnd(C, seed=322)
+    out = ops().group_norm(x, gamma, beta, 32, 1e-6, nimg)
+    ref = F.group_norm(x.float().transpose(1, 2), 32, gamma.float(), beta.float(), 1e-6).transpose(1, 2)
+    assert rel_err(out, ref) < 2e-3
+    try:
+        ops().set_option('gn_fuse', 0)
+        unfused = ops().group_norm(x, gamma, beta, 32, 1e-6, nimg)
+    finally:
+        ops().set_option('gn_fuse', 1)
+    assert torch.equal(out, unfused)
 
 
 @pytest.mark.parametrize('M,C', [(1000, 320), (64, 1280), (7, 64), (33, 640)])
@@ -614,14 +640,14 @@ def test_attention_query_blocks_per_wave(qb, nb, heads, nq, nk, d, kv_div):
     scale = d ** -0.5
     ref, _ = attn_ref(q, k, v, heads, scale, kv_div=kv_div)
     try:
-        ops().set_option('attn_o16', 0)         # both forms on 32-row O^T tiles (d = 40's default, the 16-row tiles, sums the keys of
+        ops().set_option('attn_o16', 0)         # both forms on 32-row O^T tiles (the default; the optional 16-row tiles sum the keys of
         ops().set_option('attn_qb', qb)         # a block in another order: test_attention_o_tiles_of_16_rows)
         out = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
         ops().set_option('attn_qb', 3 - qb)
         other = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
     finally:
         ops().set_option('attn_qb', 0)
-        ops().set_option('attn_o16', 1)
+        ops().set_option('attn_o16', 0)
     assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < 4e-3
     assert torch.equal(out, other), 'a query\'s result must not depend on how many query blocks its wave owns'
 
@@ -629,7 +655,7 @@ def test_attention_query_blocks_per_wave(qb, nb, heads, nq, nk, d, kv_div):
 @pytest.mark.parametrize('nb,heads,nq,nk,kv_div', [(2, 8, 300, 300, 1), (2, 8, 1024, 1001, 1), (4, 8, 1024, 77, 2), (1, 8, 4096, 4096, 1),
                                                    (2, 5, 96, 333, 1)])
 def test_attention_o_tiles_of_16_rows(nb, heads, nq, nk, kv_div):
-    """d = 40 (round 6): O^T on 16 x 16 x 32 MFMA tiles — 40 channel rows padded to 48 instead of 64, P^T brought into the B-operand
+    """d = 40 (round 6; option attn_o16 = 1, measured and not made the default): O^T on 16 x 16 x 32 MFMA tiles — 40 channel rows padded to 48 instead of 64, P^T brought into the B-operand
     layout by v_permlane16_swap, the rescale factors redistributed the same way, the softmax denominator from the ones row 47
     (csrc/attention.hip, O16; tools/ubench/mfma16_probe.hip probed both instructions).  Against the fp32 reference under the same
     tolerance as every attention test, and against the 32-row form (option attn_o16 = 0): the two sum a key block's products in
@@ -650,7 +676,7 @@ def test_attention_o_tiles_of_16_rows(nb, heads, nq, nk, kv_div):
         ops().set_option('attn_o16', 0)
         old = ops().attention(q, k, make_vt(v), heads, scale, kv_div=kv_div)
     finally:
-        ops().set_option('attn_o16', 1)
+        ops().set_option('attn_o16', 0)
     assert rel_err(out, ref, l2_tol=3e-3, row_tol=1.2e-2) < (6e-3 if nq >= 4096 else 4e-3)
     assert torch.equal(out, again)
     e_new, e_old = rel_err(out, ref, l2_tol=1.0, row_tol=1.0), rel_err(old, ref, l2_tol=1.0, row_tol=1.0)

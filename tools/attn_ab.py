@@ -77,7 +77,7 @@ def main():
             errs.append(f'{tag}{x}: rel-L2 {float((o - ref).norm() / ref.norm()):.3e} max {float((o - ref).abs().max()):.2e}')
         print(f'accuracy nb={nb} n={n} d={d}: ' + '  '.join(errs), flush=True)
     ops.set_option('attn_qb', 0)
-    ops.set_option('attn_o16', 1)
+    ops.set_option('attn_o16', 0)
 
 
 if __name__ == '__main__':

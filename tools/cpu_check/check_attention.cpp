@@ -68,7 +68,7 @@ static void report(const char* name, int rc, const std::vector<double>& want, co
 }
 
 // softmax(scale Q K^T) V per (batch, head); K / V batches are shared by kv_div query batches (CFG halves, frames of a clip)
-static long g_attn_var = 0, g_attn_o16 = 1;
+static long g_attn_var = 0, g_attn_o16 = 1;      // (the product's default is 0; the checks run the 16-row form unless a case says otherwise)
 namespace vsxg {
 // the option table lives in gemm.hip: "attn_qb" (query blocks per wave) and "attn_o16" (16-row O^T tiles at d = 40) are asked here
 long gemm_option(const char* name) { return strcmp(name, "attn_o16") == 0 ? g_attn_o16 : g_attn_var; }

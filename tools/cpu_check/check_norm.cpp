@@ -5,9 +5,26 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 struct float2 { float x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 #include "common.h"
+
+// wave shuffle towards lane 0 (hip/hip_runtime.h has __shfl / __shfl_xor): lanes whose partner lies past the wave keep their value
+static inline float __shfl_down(float v, int delta, int width = 64) {
+    (void)width;
+    const int lane = (int)(cpuhip::ctx.tid.x & 63);
+    cpuhip::ctx.wave_slots[lane] = v;
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    const float r = lane + delta < 64 ? cpuhip::ctx.wave_slots[lane + delta] : v;
+    cpuhip::ctx.wave_bar->arrive_and_wait();
+    return r;
+}
+static long g_gn_fuse = 1;
+namespace vsxg {
+long gemm_option(const char*) { return g_gn_fuse; }      // the option table lives in gemm.hip: only "gn_fuse" is asked here
+}
 
 int vsx_fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -79,6 +96,22 @@ static void run_groupnorm(const char* name, long nimg, long rows, long C1, long 
         rc = vsx_groupnorm_apply(x1.data(), C2 ? x2.data() : nullptr, nimg, rows, C1, C2, groups, partial.data(), nchunks, rows,
                                  gamma.data(), beta.data(), 1e-5f, silu ? 1 : 0, stats.data(), y.data(), nullptr);
     report(name, rc, want, dbl(y), 2e-3);
+    // few chunks per image: the apply kernel finalized the statistics itself (GN_FUSE_MAX_CHUNKS); with the stand-alone finalize
+    // kernel (option gn_fuse = 0) statistics and output must come out bit for bit the same
+    if (rc == 0 && nchunks <= 64) {
+        std::vector<float> stats2((size_t)nimg * groups * 2, -3.f);
+        std::vector<half_t> y2((size_t)nimg * rows * C, (half_t)-7.f);
+        g_gn_fuse = 0;
+        rc = vsx_groupnorm_apply(x1.data(), C2 ? x2.data() : nullptr, nimg, rows, C1, C2, groups, partial.data(), nchunks, rows,
+                                 gamma.data(), beta.data(), 1e-5f, silu ? 1 : 0, stats2.data(), y2.data(), nullptr);
+        g_gn_fuse = 1;
+        const bool same = rc == 0 && memcmp(stats.data(), stats2.data(), stats.size() * sizeof(float)) == 0 &&
+                          memcmp(y.data(), y2.data(), y.size() * sizeof(half_t)) == 0;
+        printf("%-64s %s\n", "  fused finalize (in the apply kernel) == stand-alone finalize, bit for bit", same ? "ok" : "FAIL");
+        if (!same) ++n_bad;
+    } else if (rc == 0) {
+        printf("%-64s (%ld chunks per image: stand-alone finalize)\n", "  ", nchunks);
+    }
 }
 
 static void run_layernorm(const char* name, long M, long C, bool pe, long rows_per_frame, long frames, long frame_offset) {

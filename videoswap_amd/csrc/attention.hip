@@ -65,7 +65,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 //     -> 3.1e-4: dropped.
 // Neither operand delivery nor the VALU instruction count is what bounds this kernel at d = 40: the time is close to
 // (MFMA issue + VALU issue) of a SIMD's waves added up, 29 % of the MFMA work being the 40 -> 48 / 40 -> 64 padding.
-// O16 (round 6, d = 40 only): the second product on 16 x 16 x 32 MFMA tiles.  With 32 x 32 tiles O^T pads 40 channel rows to 64
+// O16 (round 6, d = 40 only; option attn_o16, off by default — see launch_attn): the second product on 16 x 16 x 32 MFMA tiles.  With 32 x 32 tiles O^T pads 40 channel rows to 64
 // (8 MFMAs of 32 cycles per 64-key tile, 37.5 % of them multiplying padding); with 16-row tiles it pads to 48: 2 key blocks x 3
 // row tiles x 2 query tiles = 12 MFMAs of 16 cycles (tools/ubench/mfma16_probe.hip: 17 against 32 ticks per instruction), 192
 // instead of 256 matrix-pipe cycles per key tile of a kernel whose time is MFMA issue + VALU issue added up.  What it takes:
@@ -456,8 +456,11 @@ int launch_attn(const AttnParams& p, long nb, hipStream_t stream) {
     }
     dim3 grid((unsigned)(((p.nq + 127) / 128) * (long)p.heads * nb));
     if constexpr (D == 40) {
-        // 16-row O^T tiles (flash_attn_kernel, O16): the inference path of every d = 40 launch; option "attn_o16" / VSX_ATTN_O16 = 0 keeps
-        // the 32-row tiles (A/B runs, equality tests), and the log-sum-exp output of the training step stays on them
+        // 16-row O^T tiles (flash_attn_kernel, O16): option "attn_o16" / VSX_ATTN_O16 = 1.  Built and measured in round 6
+        // and NOT the default: 64 of 448 matrix-pipe cycles per key tile fewer, but the kernel does not get faster for it — 613.8 -> 602.3 TF/s
+        // at 32 x 8 heads x 4096^2, 629.7 -> 650.6 at 16 images, 642.5 -> 648.1 at 5376 keys, 4.040 -> 4.039 frames/s end to end on one box
+        // (profiles/r06_attn_o16_ab.txt): per 64-key tile a wave issues 164 VALU instructions — 33 v_exp_f32 among them, at a quarter of the
+        // plain rate — beside its 14 MFMAs, and it is that stream, not the padding of O^T, that sets the tile time at d = 40.
         if (p.lse == nullptr && vsxg::gemm_option("attn_o16") != 0) {
             hipLaunchKernelGGL((flash_attn_kernel<D, 1, true>), grid, dim3(256), 0, stream, p);
             return vsx_check_launch("vsx_attention_f16");

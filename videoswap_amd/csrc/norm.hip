@@ -3,6 +3,10 @@
 // fp32 statistics, deterministic reduction order (no atomics).
 #include "common.h"
 
+namespace vsxg {
+long gemm_option(const char* name);      // gemm.hip: the option table of vsx_set_option
+}
+
 namespace {
 
 constexpr int GN_MAX_THREADS = 512;
@@ -107,6 +111,19 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void gn_stats_kernel(const half_t* 
     }
 }
 
+// mean / rstd from the two sums of an (image, group): ONE spelling for the stand-alone finalize kernel and for the apply kernel's fused
+// prologue (explicit fma: the two must round alike whatever the compiler would contract)
+__device__ __forceinline__ void gn_mean_rstd(const float sum, const float sumsq, const float inv_count, const float eps, float& mean,
+                                             float& rstd) {
+    mean = sum * inv_count;
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, sumsq * inv_count), 0.f);
+    rstd = rsqrtf(var + eps);
+}
+
+// The apply kernel computes the statistics itself when an image has at most this many chunks (the per-frame GroupNorms of the
+// transformer / motion-module entries: 13 - 49 chunks per image): one launch fewer per GroupNorm, 36 of 81 per UNet forward.
+constexpr int GN_FUSE_MAX_CHUNKS = 64;
+
 // grid (groups, nimg), block 256: mean / rstd of one (image, group) from its per-chunk partial sums.  The 5-D
 // GroupNorm has ~1000 chunks per image: every thread issues its (independent) loads back to back and the combine is
 // a fixed-shape tree, so the kernel is a few microseconds and the result is deterministic (identical on every rank).
@@ -135,10 +152,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         __syncthreads();
     }
     if (tid == 0) {
-        const float mean = s_a[0] * inv_count;
-        const float var = fmaxf(s_b[0] * inv_count - mean * mean, 0.f);
+        float mean, rstd;
+        gn_mean_rstd(s_a[0], s_b[0], inv_count, eps, mean, rstd);
         stats[(img * groups + g) * 2] = mean;
-        stats[(img * groups + g) * 2 + 1] = rsqrtf(var + eps);
+        stats[(img * groups + g) * 2 + 1] = rstd;
     }
 }
 
@@ -146,11 +163,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // b = beta - mean * a) of the thread's own eight channels are built once, in registers, so the streaming loop is one FMA
 // (+ SiLU) per element and touches no LDS (the first version recomputed the group index with an integer division per element
 // and was VALU-bound; the second kept the constants in an LDS table and read 64 bytes of it per 16-byte vector).
+// FUSED (nchunks <= GN_FUSE_MAX_CHUNKS, no finalize launch): `partial` holds the image's per-chunk sums [nchunks][groups][2]; every
+// workgroup reduces them itself — wave w takes groups w, w + nwaves, ..: lane l holds chunk l (zero past nchunks) and the wave adds
+// with partners l + 32, l + 16, .., l + 1, which is the tree of gn_finalize_kernel restricted to its first 64 slots (the slots past
+// the chunk count hold zeros there, and x + 0 is x): the same sums in the same order, the same gn_mean_rstd — bit-identical
+// statistics — and the workgroups with blockIdx.x == 0 still write them to `stats_out` (the C ABI hands them to the caller).
+template <bool FUSED>
 __global__ __launch_bounds__(GN_MAX_THREADS) void gn_apply_kernel(const half_t* __restrict__ x1, const half_t* __restrict__ x2,
                                                                   long rows, int C1, int C2, int groups,
                                                                   const float* __restrict__ stats,
                                                                   const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
-                                                                  int silu, half_t* __restrict__ y) {
+                                                                  int silu, half_t* __restrict__ y, const float* __restrict__ partial,
+                                                                  int nchunks, float inv_count, float eps, float* __restrict__ stats_out) {
     const int C = C1 + C2;
     const int cpg = C / groups;
     const int vpr = C >> 3;
@@ -159,10 +183,37 @@ __global__ __launch_bounds__(GN_MAX_THREADS) void gn_apply_kernel(const half_t* 
     const int rl = tid / vpr;
     const int c0 = (tid - rl * vpr) * 8;
     const long img = blockIdx.y;
+    __shared__ float st_sh[FUSED ? 2 * GN_MAX_GROUPS : 2];
+    if constexpr (FUSED) {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int nwaves = (int)blockDim.x >> 6;                    // full waves only (480 threads: 7; the half wave idles here)
+        if (wave < nwaves) {
+            const float2* pp = reinterpret_cast<const float2*>(partial) + img * nchunks * groups;
+            for (int g = wave; g < groups; g += nwaves) {
+                float2 v = lane < nchunks ? pp[(long)lane * groups + g] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int w = 32; w > 0; w >>= 1) {
+                    v.x += __shfl_down(v.x, w, 64);
+                    v.y += __shfl_down(v.y, w, 64);
+                }
+                if (lane == 0) {
+                    float mean, rstd;
+                    gn_mean_rstd(v.x, v.y, inv_count, eps, mean, rstd);
+                    st_sh[2 * g] = mean;
+                    st_sh[2 * g + 1] = rstd;
+                    if (blockIdx.x == 0) {
+                        stats_out[(img * groups + g) * 2] = mean;
+                        stats_out[(img * groups + g) * 2 + 1] = rstd;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
     float ca[8], cb[8];
     {
         const h8 gm = as_h8(ld16(gamma + c0)), bt = as_h8(ld16(beta + c0));
-        const float* st = stats + img * groups * 2;
+        const float* st = FUSED ? st_sh : stats + img * groups * 2;
         int g = c0 / cpg, left = (g + 1) * cpg - c0;      // channels of group g from c0 on
         float mean = st[2 * g], rstd = st[2 * g + 1];
 #pragma unroll
@@ -429,13 +480,22 @@ extern "C" int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg,
                 "groupnorm_apply: gamma/beta/y must be 16-byte aligned");
     const int64_t C = C1 + C2;
     const float inv_count = 1.0f / ((float)count_rows * (float)(C / groups));
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)groups, (unsigned)nimg), dim3(256), 0, (hipStream_t)stream, partial,
-                       (int)nchunks, (int)groups, inv_count, eps, stats);
     const int rpb = gn_apply_rows(rows, nimg);
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nimg);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3((unsigned)gn_threads((int)C)), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
+    const unsigned threads = (unsigned)gn_threads((int)C);
+    // few chunks per image (per-frame GroupNorm): the apply kernel finalizes the statistics itself — one launch fewer; option
+    // "gn_fuse" / VSX_GN_FUSE = 0 keeps the stand-alone finalize kernel (A/B runs, the equality test)
+    if (nchunks <= GN_FUSE_MAX_CHUNKS && threads >= 64 && vsxg::gemm_option("gn_fuse") != 0) {
+        hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(threads), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
+                           (long)rows, (int)C1, (int)C2, (int)groups, (const float*)nullptr, (const half_t*)gamma, (const half_t*)beta,
+                           (int)silu, (half_t*)y, partial, (int)nchunks, inv_count, eps, stats);
+        return vsx_check_launch("vsx_groupnorm_apply");
+    }
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)groups, (unsigned)nimg), dim3(256), 0, (hipStream_t)stream, partial,
+                       (int)nchunks, (int)groups, inv_count, eps, stats);
+    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(threads), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
                        (long)rows, (int)C1, (int)C2, (int)groups, stats, (const half_t*)gamma, (const half_t*)beta,
-                       (int)silu, (half_t*)y);
+                       (int)silu, (half_t*)y, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr);
     return vsx_check_launch("vsx_groupnorm_apply");
 }
 
