@@ -478,32 +478,32 @@ def test_group_norm(nimg, rows, C1, C2, groups, silu):
     if silu:
         ref = F.silu(ref)
     assert rel_err(out, ref) < 2e-3
-    # few chunks per image (the per-frame GroupNorms): the apply kernel finalizes the statistics itself (round 6: one launch fewer);
-    # the stand-alone finalize kernel (option gn_fuse = 0) must give the same bits
+    # few chunks per image (the per-frame GroupNorms): the apply kernel can finalize the statistics itself (option gn_fuse = 1, round 6:
+    # one launch fewer; measured 2 % slower and left off) — same bits as the stand-alone finalize kernel
     try:
-        ops().set_option('gn_fuse', 0)
-        unfused = ops().group_norm(x, gamma, beta, groups, 1e-5, nimg, silu=silu, x2=x2)
-    finally:
         ops().set_option('gn_fuse', 1)
-    assert torch.equal(out, unfused)
+        fused = ops().group_norm(x, gamma, beta, groups, 1e-5, nimg, silu=silu, x2=x2)
+    finally:
+        ops().set_option('gn_fuse', 0)
+    assert torch.equal(out, fused)
 
 
 @pytest.mark.parametrize('nimg,rows,C', [(16, 4096, 320), (32, 4096, 320), (64, 1024, 640), (32, 256, 1280), (128, 64, 1280), (1, 65536, 320)])
 def test_group_norm_fused_finalize_at_the_model_shapes(nimg, rows, C):
     """The GroupNorms in front of `proj_in` (attention.py:61,110; motion_module.py:112,149) at the UNet's real shapes — per frame, 13 - 49
-    chunks per image: statistics finalized inside the apply kernel — and the 5-D GroupNorm of a resnet at B = 1 (771 chunks: the
-    stand-alone finalize kernel stays): against PyTorch, and fused == unfused bit for bit."""
+    chunks per image: statistics optionally finalized inside the apply kernel (gn_fuse = 1) — and the 5-D GroupNorm of a resnet at B = 1
+    (771 chunks: always the stand-alone finalize kernel): against PyTorch, and fused == unfused bit for bit."""
     x = rnd(nimg, rows, C, seed=320) * 1.5 + 0.3
     gamma, beta = rnd(C, seed=321) + 1.0, rnd(C, seed=322)
     out = ops().group_norm(x, gamma, beta, 32, 1e-6, nimg)
     ref = F.group_norm(x.float().transpose(1, 2), 32, gamma.float(), beta.float(), 1e-6).transpose(1, 2)
     assert rel_err(out, ref) < 2e-3
     try:
-        ops().set_option('gn_fuse', 0)
-        unfused = ops().group_norm(x, gamma, beta, 32, 1e-6, nimg)
-    finally:
         ops().set_option('gn_fuse', 1)
-    assert torch.equal(out, unfused)
+        fused = ops().group_norm(x, gamma, beta, 32, 1e-6, nimg)
+    finally:
+        ops().set_option('gn_fuse', 0)
+    assert torch.equal(out, fused)
 
 
 @pytest.mark.parametrize('M,C', [(1000, 320), (64, 1280), (7, 64), (33, 640)])

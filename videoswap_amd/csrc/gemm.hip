@@ -1054,7 +1054,7 @@ struct Option { const char* name; const char* env; long value; bool init; };
 Option g_options[] = {{"gemm_pp", "VSX_GEMM_PP", 1, false}, {"pp_sched", "VSX_PP_SCHED", 0, false},
                       {"tile_tune", "VSX_TUNE_TILE", 0, false}, {"xcd_walk", "VSX_XCD_WALK", 1, false},
                       {"attn_qb", "VSX_ATTN_QB", 0, false}, {"temporal_out", "VSX_TEMPORAL_OUT", 0, false},
-                      {"attn_o16", "VSX_ATTN_O16", 0, false}, {"gn_fuse", "VSX_GN_FUSE", 1, false}};
+                      {"attn_o16", "VSX_ATTN_O16", 0, false}, {"gn_fuse", "VSX_GN_FUSE", 0, false}};
 Option* find_option(const char* name) {
     for (auto& o : g_options)
         if (strcmp(o.name, name) == 0) {

@@ -120,8 +120,9 @@ __device__ __forceinline__ void gn_mean_rstd(const float sum, const float sumsq,
     rstd = rsqrtf(var + eps);
 }
 
-// The apply kernel computes the statistics itself when an image has at most this many chunks (the per-frame GroupNorms of the
-// transformer / motion-module entries: 13 - 49 chunks per image): one launch fewer per GroupNorm, 36 of 81 per UNet forward.
+// The apply kernel can compute the statistics itself when an image has at most this many chunks (the per-frame GroupNorms of the
+// transformer / motion-module entries: 13 - 49 chunks per image): one launch fewer per GroupNorm, 36 of 81 per UNet forward (option
+// gn_fuse; measured, not the default: vsx_groupnorm_apply).
 constexpr int GN_FUSE_MAX_CHUNKS = 64;
 
 // grid (groups, nimg), block 256: mean / rstd of one (image, group) from its per-chunk partial sums.  The 5-D
@@ -483,8 +484,11 @@ extern "C" int vsx_groupnorm_apply(const void* x1, const void* x2, int64_t nimg,
     const int rpb = gn_apply_rows(rows, nimg);
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)nimg);
     const unsigned threads = (unsigned)gn_threads((int)C);
-    // few chunks per image (per-frame GroupNorm): the apply kernel finalizes the statistics itself — one launch fewer; option
-    // "gn_fuse" / VSX_GN_FUSE = 0 keeps the stand-alone finalize kernel (A/B runs, the equality test)
+    // few chunks per image (per-frame GroupNorm): the apply kernel can finalize the statistics itself — one launch fewer; option
+    // "gn_fuse" / VSX_GN_FUSE = 1.  Built and measured in round 6 and NOT the default: bit-identical, but 2 % SLOWER over the 60 per-frame
+    // GroupNorms of a forward pair (0.874 -> 0.894 ms, profiles/r06_groupnorm_fused_finalize_ab.txt) — a 4-us finalize launch between two
+    // kernels costs less than the same reduction on the critical path of every apply workgroup (back-to-back launches overlap their
+    // ramp-up and drain; a prologue does not)
     if (nchunks <= GN_FUSE_MAX_CHUNKS && threads >= 64 && vsxg::gemm_option("gn_fuse") != 0) {
         hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(threads), 0, (hipStream_t)stream, (const half_t*)x1, (const half_t*)x2,
                            (long)rows, (int)C1, (int)C2, (int)groups, (const float*)nullptr, (const half_t*)gamma, (const half_t*)beta,
