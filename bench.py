@@ -451,7 +451,9 @@ def main():
     prof = args.prof_samples > 0 and device.type == 'cuda'
     if prof:
         ops.prof_enable(True, args.prof_samples, stride=args.prof_stride)
-    elapsed = timed_clips(run_clip, batches, args.ddim_steps, args.steps, barrier, marks)
+    from videoswap_amd.telemetry import BoardPower
+    with BoardPower(local_rank if device.type == 'cuda' else -1) as bpw:      # host thread reading sysfs: nothing on the stream
+        elapsed = timed_clips(run_clip, batches, args.ddim_steps, args.steps, barrier, marks)
     # device time of the two halves of every clip (events on the launch stream; nothing was synchronised in between)
     inv_s = sum(marks[3 * i].elapsed_time(marks[3 * i + 1]) for i in range(args.steps)) * 1e-3
     smp_s = sum(marks[3 * i + 1].elapsed_time(marks[3 * i + 2]) for i in range(args.steps)) * 1e-3
@@ -504,6 +506,8 @@ def main():
                      'loop_mfma_frac': round(total_flop / elapsed / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
                      'ceiling_R1e_at_100pct_mfma': 15.1},
     }
+    if bpw.summary() is not None:           # rank 0's board over the timed region (MI355X: 1 400 W cap)
+        out['readings']['board_power'] = bpw.summary()
     if distributed and world == 1:
         out['config']['forced_distributed'] = 'VSX_FORCE_DISTRIBUTED=1: the multi-rank branches on one rank (%s)' % dist.get_backend()
     if longclip and not stub:
@@ -534,7 +538,8 @@ def main():
             barrier()
             if prof:
                 ops.prof_enable(True, args.prof_samples, stride=args.prof_stride)
-            t2 = timed_clips(run_clip, tb, args.ddim_steps, nb, barrier)
+            with BoardPower(local_rank) as bpw2:
+                t2 = timed_clips(run_clip, tb, args.ddim_steps, nb, barrier)
             roof2 = ops.prof_collect_roofline(MFMA_PEAK_TFLOPS * 1e12, HBM_COPY_TBPS * 1e12) if prof else dict(n=0, ms=0.0)
             if prof:
                 ops.prof_enable(False, 0)
@@ -544,7 +549,8 @@ def main():
                 'ms_per_step': round(1e3 * t2 / nb, 1), 'ratio_to_value': round(v2 / value, 4),
                 'latents': [tcl, 4, args.frames, lh, lw],
                 'workload': workload_string(args, tcl, lh, lw),
-                'roofline': roofline_object(roof2, t2, args.prof_stride, (args.frames, args.latent if plain else -1, tcl))}
+                'roofline': roofline_object(roof2, t2, args.prof_stride, (args.frames, args.latent if plain else -1, tcl)),
+                'board_power': bpw2.summary()}
             del extra, tb
         except Exception as e:  # the second leg must never take the headline down with it
             out['throughput_mode'] = {'clips_per_step': tcl, 'value': None, 'note': f'failed: {e!r}'}

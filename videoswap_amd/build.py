@@ -257,7 +257,35 @@ def build_from_git(name, rev, verbose=True):
     return lib
 
 
+def build_with_defines(name, defines, verbose=True):
+    """lib/libvsx_<name>.so from the CURRENT sources with extra -D flags (ablation builds for tools/gemm_ab.py --libs: what an
+    epilogue costs without its stores / its activation ...).  Never the product: no digest, no scratch check, results may be wrong."""
+    objdir = os.path.join(LIBDIR, f'obj_{name}')
+    os.makedirs(objdir, exist_ok=True)
+
+    def one(n):
+        obj = os.path.join(objdir, n + '.o')
+        extra = [f'-DVSX_SOURCE_DIGEST="defines-{name}"'] if n == 'api.cpp' else []
+        r = subprocess.run([HIPCC] + FLAGS + list(defines) + extra + ['-c', os.path.join(CSRC, n), '-o', obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {n} ({defines}):\n{r.stderr}')
+        return obj
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(one, SOURCES))
+    lib = lib_path(name)
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs + ['-ldl'], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stderr}')
+    if verbose:
+        print(f'[vsx] built {lib} with {" ".join(defines)}')
+    return lib
+
+
 if __name__ == '__main__':
+    if '--define' in sys.argv:                         # --define NAME -DFLAG[=v] [-DFLAG2 ...]
+        _i = sys.argv.index('--define')
+        build_with_defines(sys.argv[_i + 1], [a for a in sys.argv[_i + 2:] if a.startswith('-D')])
+        sys.exit(0)
     if '--from-git' in sys.argv:                       # --from-git NAME REV
         _i = sys.argv.index('--from-git')
         build_from_git(sys.argv[_i + 1], sys.argv[_i + 2])

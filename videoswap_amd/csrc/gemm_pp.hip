@@ -39,6 +39,14 @@
 
 #include <stdlib.h>
 
+// -DVSX_PP_ABLATE=<bits> (python -m videoswap_amd.build --define <name> -DVSX_PP_ABLATE=n -> lib/libvsx_<name>.so, tools/gemm_ab.py --libs):
+// ablation builds that answer "what does the epilogue cost" by leaving parts of it out — 1: no global stores of C, 2: no GELU
+// (GEGLU writes h * g).  WRONG RESULTS by construction; never defined in the product build (profiles/r06_gemm_epilogue_ablation.txt).
+// (Leaving the whole epilogue out is not a measurement: the compiler then drops the MFMAs whose accumulators nobody reads.)
+#ifndef VSX_PP_ABLATE
+#define VSX_PP_ABLATE 0
+#endif
+
 namespace vsxg {
 #ifdef VSX_GEMM_TIMING
 // -DVSX_GEMM_TIMING (tools/gemm_timing.py pp ...): per-wave cycle totals long[workgroup][wave][4] = main loop (all K slabs of
@@ -207,7 +215,7 @@ __device__ __forceinline__ void epilogue_rows(kparams_t p, const float* stg, con
             const unsigned q = r / Ws, j = r - q * Ws;
             const unsigned orow = 4u * Ws * q + 2u * j + 2u * Ws * (cls >> 1) + (cls & 1u);
             if (m < Mi) *reinterpret_cast<h8*>(cp + (orow * ldc + (unsigned)n)) = pk;
-        } else if (m < Mi) *reinterpret_cast<h8*>(cp + ((unsigned)m * ldc + (unsigned)n)) = pk;
+        } else if ((VSX_PP_ABLATE & 1) ? m < -Mi : m < Mi) *reinterpret_cast<h8*>(cp + ((unsigned)m * ldc + (unsigned)n)) = pk;
         if constexpr (STATS) {
             // v_dot2_f32_f16 on the packed pairs: sum and sum of squares of the rounded values without converting them back
             // (8 instructions per pass instead of 24; fp16 x fp16 products are exact in fp32)
@@ -427,7 +435,8 @@ __device__ __forceinline__ void epilogue_pp(f16v (&acc)[5][TM], float* stg, cons
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { hv[e] += bh[e]; gv[e] += bg[e]; }
                         }
-                        const vsx_f2 g01 = gelu_erf_f2(vsx_f2{gv[0], gv[1]}), g23 = gelu_erf_f2(vsx_f2{gv[2], gv[3]});
+                        const vsx_f2 g01 = (VSX_PP_ABLATE & 2) ? vsx_f2{gv[0], gv[1]} : gelu_erf_f2(vsx_f2{gv[0], gv[1]});
+                        const vsx_f2 g23 = (VSX_PP_ABLATE & 2) ? vsx_f2{gv[2], gv[3]} : gelu_erf_f2(vsx_f2{gv[2], gv[3]});
                         const f4v o = {hv[0] * g01[0], hv[1] * g01[1], hv[2] * g23[0], hv[3] * g23[1]};
                         *reinterpret_cast<f4v*>(stg + l31 * stride + jj * 16 + 8 * q + 4 * hi) = o;
                     }
