@@ -35,9 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-# what the power-managed clock sustains with all 256 CUs streaming MFMAs: 1.75 of 2.4 GHz (profiles/r03_ubench_clock_probe.txt);
-# reported beside the nominal peak, never instead of it
-MFMA_SUSTAINED_TFLOPS = 1820.0
+# what a register-resident stream of v_mfma_f32_32x32x16_f16 delivers on normal(0, 1) fp16 operands with all 256 CUs busy: the board's
+# power / current management holds the shader clock at 1.55 - 1.76 GHz (profiles/r06_ubench_mfma_power.txt: 1 580 / 1 679 TF/s on two
+# boxes; 2 459 - 2 467 on zeros at 2.40 GHz).  Reported beside the nominal peak, never instead of it.
+MFMA_REAL_DATA_TFLOPS = 1630.0
+NOMINAL_SCLK_MHZ = 2400.0
 FRAME_EVAL_TFLOP = 1.1046     # algorithmic TFLOP of one frame-evaluation at T=16, 64x64
 HBM_COPY_TBPS = 6.29          # measured float4-copy rate, /opt/skills/guides/MI355X_MICROARCH.md (8.0 TB/s spec): the byte roofline
 
@@ -508,6 +510,7 @@ def main():
     }
     if bpw.summary() is not None:           # rank 0's board over the timed region (MI355X: 1 400 W cap)
         out['readings']['board_power'] = bpw.summary()
+        out['readings']['board_power']['joules_per_frame'] = round(bpw.summary()['mean_W'] * elapsed / max(frames_total / world, 1), 1)
     if distributed and world == 1:
         out['config']['forced_distributed'] = 'VSX_FORCE_DISTRIBUTED=1: the multi-rank branches on one rank (%s)' % dist.get_backend()
     if longclip and not stub:
@@ -517,11 +520,18 @@ def main():
     plain = lh == lw == args.latent and args.config == 2
     rl = roofline_object(roof, elapsed, args.prof_stride, (args.frames, args.latent if plain else -1, cps))
     if rl is not None:
-        # footnote, not a roofline: what the power-managed clock sustains under chip-wide MFMA load on these boxes
-        out['readings']['gemm_tflops_vs_sustained_clock_peak'] = {
-            'peak_sustained': MFMA_SUSTAINED_TFLOPS, 'frac': round(rl['achieved'] / MFMA_SUSTAINED_TFLOPS, 4),
-            'source': 'core clock 1.75 GHz with all 256 CUs streaming MFMAs (tools/ubench/clock_probe.hip); the guide '
-                      'measures 2 495 TF dense, which is the peak the roofline object prices against'}
+        # footnotes, not rooflines: (1) the rate a bare MFMA stream reaches on real fp16 data under this board's power management,
+        # (2) the nominal peak scaled to the mean shader clock THIS run's timed region was held at (readings.board_power)
+        note = {'mfma_stream_on_real_data': MFMA_REAL_DATA_TFLOPS, 'frac': round(rl['achieved'] / MFMA_REAL_DATA_TFLOPS, 4),
+                'source': 'tools/ubench/mfma_power.hip: v_mfma_f32_32x32x16_f16 on normal(0, 1) operands, registers only, 256 CUs: '
+                          '1 580 - 1 679 TF/s at 1.55 - 1.76 GHz (2 459 - 2 467 on zeros at 2.40 GHz); the roofline object prices '
+                          'against the nominal 2 500'}
+        bp = out['readings'].get('board_power') or {}
+        if bp.get('sclk_mean_MHz'):
+            pk = MFMA_PEAK_TFLOPS * bp['sclk_mean_MHz'] / NOMINAL_SCLK_MHZ
+            note['peak_at_measured_clock'] = round(pk, 1)
+            note['frac_at_measured_clock'] = round(rl['achieved'] / pk, 4)
+        out['readings']['gemm_tflops_vs_power_managed_peak'] = note
         out['roofline'] = rl
     tcl = args.throughput_clips
     if (rank == 0 and world == 1 and args.config == 2 and not args.no_extra_reading and not distributed and not stub
