@@ -773,6 +773,15 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
             self.__dict__['_native_epoch'] = Attention.processor_epoch
         return self.__dict__['_all_native']
 
+    @staticmethod
+    def _device_key(device):
+        """One spelling per device for the step caches: 'cuda' (what a caller's `pipe.to('cuda')` hands over) and 'cuda:0' (what a
+        tensor on it reports) are the same device, and a row prepared under one must be found under the other."""
+        d = torch.device(device)
+        if d.type == 'cuda' and d.index is None:
+            d = torch.device('cuda', torch.cuda.current_device())
+        return str(d)
+
     def _silu_time_embedding(self, timesteps, B, device):
         """SiLU(time_embedding(time_proj(t))) (unet.py:376-397; every consumer applies SiLU first, resnet.py:172).
         A scalar timestep gives ONE row [1, 1280] shared by the batch (the resnets broadcast it through the conv
@@ -781,7 +790,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         `time_emb_proj` results are cached on it as well (`clear_step_caches()` drops all of it)."""
         te = self.time_embedding
         if timesteps.numel() == 1:
-            key = (float(timesteps.reshape(-1)[0]), str(device), self.dtype)
+            key = (float(timesteps.reshape(-1)[0]), self._device_key(device), self.dtype)
             stamp = param_key(te.linear_1.weight, te.linear_1.bias, te.linear_2.weight, te.linear_2.bias)
             hit = self._semb_cache.get(key)
             if hit is not None and hit[0] == stamp:
@@ -812,7 +821,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         vals = [float(t) for t in (timesteps.reshape(-1).tolist() if torch.is_tensor(timesteps) else timesteps)]
         todo = []
         for v in vals:
-            hit = self._semb_cache.get((v, str(device), self.dtype))
+            hit = self._semb_cache.get((v, self._device_key(device), self.dtype))
             if (hit is None or hit[0] != stamp) and v not in todo:
                 todo.append(v)
         resnets = [m for m in self.modules() if isinstance(m, ResnetBlock3D)]
@@ -832,7 +841,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
             self._semb_cache.clear()
         for i, v in enumerate(todo):
             row = semb[i:i + 1]
-            self._semb_cache[(v, str(device), self.dtype)] = (stamp, row)
+            self._semb_cache[(v, self._device_key(device), self.dtype)] = (stamp, row)
             o = 0
             for r in resnets:
                 c = r.out_channels
@@ -857,7 +866,7 @@ class AnimateDiffUNet3DModel(ModelMixin, ConfigMixin):
         so the uploaded rows are cached per value: an H2D copy from pageable memory would otherwise drain the stream
         once per UNet call and keep the host from enqueueing ahead of the GPU."""
         if timesteps.numel() == 1:
-            key = (float(timesteps.reshape(-1)[0]), str(device), self.dtype)
+            key = (float(timesteps.reshape(-1)[0]), self._device_key(device), self.dtype)
             row = self._temb_cache.get(key)
             if row is None:
                 row = self.time_proj(timesteps.reshape(1)).to(device=device, dtype=self.dtype)
