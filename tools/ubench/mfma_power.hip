@@ -47,6 +47,28 @@ __global__ __launch_bounds__(256) void mfma_stream(const h8* __restrict__ ops, f
     sink[t] = s;
 }
 
+// Two waves per SIMD that TAKE TURNS: an 8-wave workgroup, waves 0-3 and 4-7 alternate phases of NB back-to-back MFMAs with one s_barrier
+// per phase (the persistent GEMM's ping-pong without its loads).  If the 2 / 3 of the freely interleaved streams is an arbitration effect, this
+// form is not subject to it.
+template <int NB>
+__global__ __launch_bounds__(512) void mfma_pingpong(const h8* __restrict__ ops, float* sink, int iters) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    h8 a[4], b[4];
+    for (int i = 0; i < 4; ++i) { a[i] = ops[(size_t)t * 8 + i]; b[i] = ops[(size_t)t * 8 + 4 + i]; }
+    f16v c16[8] = {};
+    for (int it = 0; it < iters; ++it) {
+        if ((it & 1) == grp) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) c16[k & 7] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k & 3], b[(k >> 1) & 3], c16[k & 7], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();
+    }
+    float s = 0.f;
+    for (int k = 0; k < 8; ++k) s += c16[k][0];
+    sink[t] = s;
+}
+
 static std::string read_file(const std::string& p) {
     FILE* f = fopen(p.c_str(), "r");
     if (!f) return "";
@@ -91,9 +113,11 @@ int main(int argc, char** argv) {
     printf("%-74s %8s %8s %8s %9s %9s\n", "MFMA stream (registers only)", "TF/s", "W mean", "W max", "MHz mean", "pJ/FLOP");
     for (int data = 0; data < 2; ++data)
         for (int kind : {32, 16})
-            for (int wcfg : {1, 2, 4, -2}) {      // -2: two waves per SIMD, the second one at s_setprio 3
-                const int wps = wcfg < 0 ? -wcfg : wcfg, prio_from = wcfg < 0 ? cus : 0;
-                const int blocks = cus * wps, threads = 256;          // 4 waves per block = 1 per SIMD; wps blocks per CU
+            for (int wcfg : {1, 2, 4, -2, -8, -16}) {      // -2: two waves per SIMD, the second one at s_setprio 3; -8 / -16: ping-pong phases of 8 / 16 MFMAs
+                if (wcfg <= -8 && kind != 32) continue;
+                const bool pp = wcfg <= -8;
+                const int wps = pp ? 2 : (wcfg < 0 ? -wcfg : wcfg), prio_from = (wcfg == -2) ? cus : 0;
+                const int blocks = pp ? cus : cus * wps, threads = pp ? 512 : 256;          // 4 waves per block = 1 per SIMD; wps blocks per CU
                 const size_t n = (size_t)blocks * threads;
                 std::vector<h8> host(n * 8);
                 srand(7);
@@ -109,7 +133,9 @@ int main(int argc, char** argv) {
                 hipMemcpy(dops, host.data(), n * 8 * sizeof(h8), hipMemcpyHostToDevice);
                 const int iters = 20000;
                 auto launch = [&] {
-                    if (kind == 16) hipLaunchKernelGGL(mfma_stream<16>, dim3(blocks), dim3(threads), 0, 0, dops, dsink, iters, prio_from);
+                    if (wcfg == -8) hipLaunchKernelGGL(mfma_pingpong<8>, dim3(blocks), dim3(threads), 0, 0, dops, dsink, 2 * iters);
+                    else if (wcfg == -16) hipLaunchKernelGGL(mfma_pingpong<16>, dim3(blocks), dim3(threads), 0, 0, dops, dsink, iters);
+                    else if (kind == 16) hipLaunchKernelGGL(mfma_stream<16>, dim3(blocks), dim3(threads), 0, 0, dops, dsink, iters, prio_from);
                     else hipLaunchKernelGGL(mfma_stream<32>, dim3(blocks), dim3(threads), 0, 0, dops, dsink, iters, prio_from);
                 };
                 launch();
@@ -135,7 +161,8 @@ int main(int argc, char** argv) {
                 }
                 stop = true;
                 sampler.join();
-                const double flop_per_launch = (double)n / 64 * iters * (kind == 16 ? 16 : 8) * 32768.0 / (kind == 16 ? 2 : 1);
+                const double flop_per_launch = pp ? (double)n / 64 * iters * 8 * 32768.0      // NB = 8: 2 * iters / 2 phases of 8; NB = 16: iters / 2 phases of 16
+                                                 : (double)n / 64 * iters * (kind == 16 ? 16 : 8) * 32768.0 / (kind == 16 ? 2 : 1);
                 const double tf = flop_per_launch * launches / dt / 1e12;
                 double pm = 0, px = 0, cm = 0;
                 const size_t skip = pw.size() / 4;
@@ -144,7 +171,7 @@ int main(int argc, char** argv) {
                 pm /= (pw.size() - skip ? pw.size() - skip : 1);
                 cm /= (ck.size() - skip ? ck.size() - skip : 1);
                 char name[128];
-                snprintf(name, 128, "v_mfma_f32_%s_f16, %s, %d wave(s) per SIMD%s", kind == 16 ? "16x16x32" : "32x32x16", data ? "normal(0,1)" : "zeros", wps, prio_from ? ", 2nd at prio 3" : "");
+                snprintf(name, 128, "v_mfma_f32_%s_f16, %s, %d wave(s) per SIMD%s", kind == 16 ? "16x16x32" : "32x32x16", data ? "normal(0,1)" : "zeros", wps, prio_from ? ", 2nd at prio 3" : (wcfg == -8 ? ", taking turns: 8 MFMAs per phase" : (wcfg == -16 ? ", taking turns: 16 MFMAs per phase" : "")));
                 printf("%-74s %8.0f %8.0f %8.0f %9.0f %9.3f\n", name, tf, pm, px, cm, pm / tf);       // W / (TFLOP/s) = pJ per FLOP
                 fflush(stdout);
                 hipFree(dops);
