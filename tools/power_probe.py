@@ -93,6 +93,13 @@ def main():
         rate, smp = run_for(lambda: ops.group_norm(x, gam, bet, 32, 1e-5, 2, silu=True), args.seconds)
         report(f'group_norm + SiLU [2, 65536, 320] (TF/s column = GB/s moved / 1000 x 3 passes): {fam}', rate, 3.0 * Mg * 320 * 2 * 1e3, smp)
         del xc, wc, x, w, res
+    # the workgroup-per-tile kernels (two free-running workgroups per CU): the 16 x 16 / 32 x 32 convolutions of one clip per step
+    for nimg, hw, c in ((32, 16, 1280), (16, 16, 1280), (16, 32, 640), (16, 8, 1280)):
+        xc = family('normal(0, 1)', nimg, hw, hw, c)
+        wc, bc = family('normal(0, 0.02)', c, 3, 3, c, seed=9), torch.zeros(c, device=DEV, dtype=H16)
+        rate, smp = run_for(lambda: ops.conv2d(xc, wc, bc), args.seconds)
+        report(f'conv3x3 {hw}x{hw} {c}->{c}, {nimg} images (tile kernels unless persistent): normal(0, 1)', rate, 2.0 * nimg * hw * hw * c * c * 9, smp)
+        del xc, wc
     # flash attention at the 64 x 64 level (32 images, 8 heads, d = 40)
     nb, heads, n, d = 32, 8, 4096, 40
     for fam in ('zeros', 'normal(0, 1)'):
