@@ -561,6 +561,9 @@ def main():
                 'workload': workload_string(args, tcl, lh, lw),
                 'roofline': roofline_object(roof2, t2, args.prof_stride, (args.frames, args.latent if plain else -1, tcl)),
                 'board_power': bpw2.summary()}
+            if out['throughput_mode']['board_power']:
+                out['throughput_mode']['board_power']['joules_per_frame'] = round(
+                    out['throughput_mode']['board_power']['mean_W'] * t2 / (tcl * nb * args.frames), 1)
             del extra, tb
         except Exception as e:  # the second leg must never take the headline down with it
             out['throughput_mode'] = {'clips_per_step': tcl, 'value': None, 'note': f'failed: {e!r}'}
