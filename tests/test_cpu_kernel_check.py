@@ -95,7 +95,7 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
            os.path.join(src, 'check_gemm_api.cpp')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    env = {k: v for k, v in os.environ.items() if k not in ('VSX_TUNE_TILE', 'VSX_GEMM_PP', 'VSX_PP_SCHED')}
+    env = {k: v for k, v in os.environ.items() if k not in ('VSX_TUNE_TILE', 'VSX_GEMM_PP', 'VSX_PP_SCHED', 'VSX_GEMM_WS')}
     env['CPUHIP_QUICK'] = '1'          # cases 21 / 22: a subset of their sub-cases (`make -C tools/cpu_check run` walks all)
     # (13: the persistent kernel, covered above; 20: the nearest-2x convolution in its sub-pixel form against the nine-tap
     # convolution of the upsampled image, and the refusal where the persistent kernel would not run)
@@ -108,7 +108,10 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
     # prefetch behind the last slab with its exact vmcnt counts (22) — the latter also with every DMA piece landing as late as
     # the kernel's own counted waits allow (an under-counted wait multiplies a slab that has not landed: the run fails)
     # 23: the persistent kernel's transposed store through the entry point, bit for bit like the tile kernels' (gemm_pp = 4)
-    for case, late in (('21', False), ('22', True), ('23', False)):
+    # 24 (round 6): the weight-stationary K = N = 320 kernel (gemm_ws320_kernel) — bias / residual / row statistics, bit for bit like the
+    # tile kernels, with late-landing DMA: its counted waits include the stores of earlier blocks and two shortened counts in the
+    # first two blocks (either one loosened by the size of its shortening fails this run)
+    for case, late in (('21', False), ('22', True), ('23', False), ('24', True)):
         r = subprocess.run([exe, case], capture_output=True, text=True, timeout=900,
                            env=dict(env, CPUHIP_DMA='late') if late else env)
         print('late DMA' if late else '', r.stdout)

@@ -868,3 +868,39 @@ def test_errors_are_reported():
         ops().linear(x, w)
     with pytest.raises(VsxError):
         ops().linear(x.cpu(), w.cpu())
+
+
+@pytest.mark.parametrize('M', [131072, 32 * 1027, 96])
+@pytest.mark.parametrize('res,stats', [(False, False), (True, False), (False, True), (True, True)])
+def test_weight_stationary_320_matches_the_persistent_kernel(M, res, stats):
+    """gemm_ws320_kernel (csrc/gemm_pp.hip; option gemm_ws): the K = N = 320 projections of the 64 x 64 level with the weights in
+    registers and the activation streamed in 32-row blocks.  Same instruction, operand roles and k order as the other back ends and
+    the same staged row passes, so the output must agree BIT FOR BIT with the product's dispatch (and with fp32 to fp16 rounding);
+    its row statistics come in 5 parts per row instead of 6 and must add up to the same sums.  M = 32 * 1027: workgroups with 5 and 4
+    blocks (the out-of-range tail pieces); M = 96: fewer blocks than CUs."""
+    from videoswap_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M % 1000 + 2 * res + stats)
+    x = torch.randn(M, 320, device=DEV, generator=g).half()
+    w = (torch.randn(320, 320, device=DEV, generator=g) * 320 ** -0.5).half()
+    b = torch.randn(320, device=DEV, generator=g).half()
+    r = torch.randn(M, 320, device=DEV, generator=g).half() if res else None
+    outs, parts = [], []
+    try:
+        for v in (0, 2):
+            ops.set_option('gemm_ws', v)
+            y = ops.linear(x, w, b, residual=r, row_stats=stats)
+            outs.append(y.clone())
+            parts.append(getattr(y, '_vsx_rowparts', None))
+    finally:
+        ops.set_option('gemm_ws', 0)
+    assert torch.equal(outs[0], outs[1])
+    ref = x.float() @ w.float().t() + b.float() + (r.float() if res else 0.0)
+    assert float((outs[1].float() - ref).norm() / ref.norm()) < 6e-4
+    if stats:
+        assert parts[1] is not None and parts[1].shape == (M, 5, 2)
+        y = outs[1].float()
+        want = torch.stack([y.sum(1), (y * y).sum(1)], 1)
+        got = parts[1].sum(1)
+        assert float((got - want).abs().max() / want.abs().max()) < 1e-5
+        if parts[0] is not None:        # the persistent kernel's 6 parts of the same rounded outputs
+            assert float((parts[0].sum(1) - got).abs().max() / want.abs().max()) < 1e-5

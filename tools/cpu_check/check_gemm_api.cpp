@@ -413,6 +413,61 @@ int main(int argc, char** argv) {
         }
         vsx_set_option("gemm_pp", 1);
     }
+    if (only < 0 || only == nplain + 11) {
+        // the weight-stationary kernel for K = N = 320 (gemm_pp.hip, gemm_ws320_kernel; option gemm_ws = 2: every eligible problem): 21
+        // blocks of 32 rows over 8 workgroups (3 / 2 blocks each, so the out-of-range tail pieces are issued), bit for bit like the tile
+        // kernels, with and without residual; with row statistics: 5 parts per row that add up to the sums of the rounded outputs
+        for (int res = 0; res < 2; ++res)
+            for (int st = 0; st < 2; ++st) {
+                char name[96];
+                snprintf(name, sizeof name, "weight-stationary 672x320x320%s%s vs tile kernels", res ? " +res" : "", st ? " +stats" : "");
+                const long M = 672, N = 320, K = 320;
+                rng_state = 4242u + res;
+                auto A = randh((size_t)M * K), B = randh((size_t)N * K, 1.0f / sqrtf((float)K)), bias = randh(N), R = randh((size_t)M * N);
+                std::vector<half_t> C0((size_t)M * N, (half_t)-7.f), C1((size_t)M * N, (half_t)-7.f);
+                std::vector<float> stats((size_t)M * 5 * 2, -1.f);
+                vsx_gemm_desc d{};
+                d.M = M; d.N = N; d.K = K; d.batch0 = d.batch1 = 1;
+                d.A = A.data(); d.lda = K; d.B = B.data(); d.ldb = K; d.ldc = N; d.bias = bias.data();
+                if (res) { d.residual = R.data(); d.ldr = N; }
+                d.alpha = 1.0; d.pad_lo = d.pad_hi = -1;
+                d.C = C0.data();
+                vsx_set_option("gemm_pp", 0);
+                vsx_set_option("gemm_ws", 0);
+                const int rc0 = vsx_gemm_f16(&d, nullptr);
+                d.C = C1.data();
+                vsx_set_option("gemm_pp", 1);
+                vsx_set_option("gemm_ws", 2);
+                if (st) {
+                    const long parts = vsx_gemm_rowstats_parts(&d);
+                    if (parts != 5) { printf("%-58s rowstats parts %ld (want 5) FAIL\n", name, parts); ++n_bad; }
+                    d.rowstats = stats.data(); d.rowstats_parts = 5;
+                }
+                const int rc1 = vsx_gemm_f16(&d, nullptr);
+                vsx_set_option("gemm_ws", 0);
+                bool same = rc0 == 0 && rc1 == 0 && memcmp(C0.data(), C1.data(), C0.size() * sizeof(half_t)) == 0;
+                double worst = 0;
+                if (st)
+                    for (long m = 0; m < M; ++m) {
+                        double s1 = 0, s2 = 0, w1 = 0, w2 = 0;
+                        for (int part = 0; part < 5; ++part) { s1 += stats[(m * 5 + part) * 2]; s2 += stats[(m * 5 + part) * 2 + 1]; }
+                        for (long n = 0; n < N; ++n) { const double v = (double)C1[m * N + n]; w1 += v; w2 += v * v; }
+                        worst = fmax(worst, fmax(fabs(s1 - w1) / (1.0 + fabs(w1)), fabs(s2 - w2) / (1.0 + fabs(w2))));
+                    }
+                if (!same && getenv("CPUHIP_VERBOSE")) {
+                    long bad = 0, first = -1;
+                    for (long i = 0; i < M * N; ++i) if (memcmp(&C0[i], &C1[i], 2)) { if (first < 0) first = i; ++bad; }
+                    printf("    %ld of %ld elements differ, first at row %ld col %ld: %f vs %f\n", bad, M * N, first / N, first % N, (double)C0[first], (double)C1[first]);
+                    long colbad[5] = {0, 0, 0, 0, 0};
+                    for (long i = 0; i < M * N; ++i) if (memcmp(&C0[i], &C1[i], 2)) ++colbad[(i % N) / 64];
+                    printf("    per 64-column block: %ld %ld %ld %ld %ld\n", colbad[0], colbad[1], colbad[2], colbad[3], colbad[4]);
+                }
+                if (worst > 1e-4) same = false;
+                printf("%-58s rc %d %d  %s%s\n", name, rc0, rc1, same ? "bit-identical" : "FAIL", st ? (worst <= 1e-4 ? ", statistics ok" : ", statistics off") : "");
+                n_bad += same ? 0 : 1;
+            }
+        vsx_set_option("gemm_pp", 1);
+    }
     printf(n_bad ? "%d check(s) FAILED\n" : "all checks passed\n", n_bad);
     return n_bad ? 1 : 0;
 }

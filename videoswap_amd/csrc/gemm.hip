@@ -1054,7 +1054,8 @@ struct Option { const char* name; const char* env; long value; bool init; };
 Option g_options[] = {{"gemm_pp", "VSX_GEMM_PP", 1, false}, {"pp_sched", "VSX_PP_SCHED", 0, false},
                       {"tile_tune", "VSX_TUNE_TILE", 0, false}, {"xcd_walk", "VSX_XCD_WALK", 1, false},
                       {"attn_qb", "VSX_ATTN_QB", 0, false}, {"temporal_out", "VSX_TEMPORAL_OUT", 0, false},
-                      {"attn_o16", "VSX_ATTN_O16", 0, false}, {"gn_fuse", "VSX_GN_FUSE", 0, false}};
+                      {"attn_o16", "VSX_ATTN_O16", 0, false}, {"gn_fuse", "VSX_GN_FUSE", 0, false},
+                      {"gemm_ws", "VSX_GEMM_WS", 1, false}};
 Option* find_option(const char* name) {
     for (auto& o : g_options)
         if (strcmp(o.name, name) == 0) {
@@ -1277,8 +1278,16 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
     const long t128 = blocks(128, 320);
     const bool pp256 = pp_ok && pp != 3 && (blocks(256, 320) >= 192 || (pp == 2 && blocks(256, 320) >= 64) || pp == 4);
     const bool pp128 = !pp256 && pp_ok && p.c_mode != 1 && ((pp >= 2 && t128 >= 32) || (pp == 1 && p.a_mode != 1 && t128 >= 240 && t128 <= 272));
-    // row statistics of the output (vsx.h, ABI 8): only the persistent kernel's staged row passes produce them
-    const long stat_parts = (pp256 || pp128) && pp_rowstats_ok(p) ? (cols / 320) * 6 : 0;
+    // Weight-stationary kernel (gemm_pp.hip: gemm_ws320_kernel) for the byte-bound K = N = 320 projections of the 64 x 64 level; option
+    // "gemm_ws" / VSX_GEMM_WS: 0 = never; 1 (default) = the projections WITH a residual from 65 536 rows (8 blocks of 32 rows per CU) —
+    // where it measured at or above the persistent kernel, alone and inside the loop (profiles/r06_gemm_weight_stationary_ab.txt:
+    // + 0.5 % frames/s at one clip per step, + 0.6 % at four; without a residual the persistent kernel's epilogue is short enough
+    // and wins); 3 = the same from 131 072 rows (A/B runs); 2 = every eligible problem (tests)
+    const long ws_opt = gemm_option("gemm_ws");
+    const bool ws = ws_opt != 0 && pp != 0 && nbatch == 1 && splits <= 1 && !force_tile() && ws_supported(p) &&
+                    (ws_opt == 2 || (d->M >= (ws_opt == 3 ? 131072 : 65536) && d->residual != nullptr));
+    // row statistics of the output (vsx.h, ABI 8): only the staged row passes of the persistent kernels produce them
+    const long stat_parts = ws ? 5 : ((pp256 || pp128) && pp_rowstats_ok(p) ? (cols / 320) * 6 : 0);
     if (dry) {
         *parts_out = stat_parts;
         return VSX_OK;
@@ -1294,7 +1303,9 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
     if (p.sp_Mc > 0)
         VSX_REQUIRE((pp256 && p.sp_Mc % 256 == 0) || (pp128 && p.sp_Mc % 128 == 0), VSX_E_UNSUPPORTED,
                     "gemm: the sub-pixel form runs on the persistent kernel only (enough tiles, rows per class a multiple of the tile)");
-    if (pp256) {
+    if (ws) {
+        rc = launch_ws(p, stream);
+    } else if (pp256) {
         rc = launch_pp(p, 256, stream);
     } else if (pp128) {
         rc = launch_pp(p, 128, stream);

@@ -94,5 +94,8 @@ long gemm_option(const char* name);
 bool pp_supported(const GemmParams& p);
 bool pp_rowstats_ok(const GemmParams& p);   // can the persistent kernel's epilogue of this problem emit row statistics?
 int launch_pp(GemmParams& p, int bm, hipStream_t stream);
+// gemm_pp.hip: weight-stationary kernel for the byte-bound K = N = 320 projections (32-row blocks streamed past register-resident weights)
+bool ws_supported(const GemmParams& p);
+int launch_ws(GemmParams& p, hipStream_t stream);
 
 }  // namespace vsxg

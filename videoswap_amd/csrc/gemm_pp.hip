@@ -967,6 +967,224 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
     return vsx_check_launch("vsx_gemm_f16 (persistent)");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// WEIGHT-STATIONARY kernel for K = N = 320 (round 6): the byte-bound projections of the 64 x 64 level (`proj 320->320 +res`,
+// proj_in with row statistics: 3.8 ms of a 79-ms step pair at 0.55 of the copy rate).  In the persistent ping-pong kernel such a
+// launch costs K loop + epilogue — the stores are 24 - 27 % of it (profiles/r06_gemm_epilogue_ablation.txt) — because the two waves
+// of a SIMD own ONE tile whose 160 accumulators leave no room for a second one.  Here the roles are swapped: the WEIGHTS stay in
+// registers (a wave owns 64 output columns: 2 x 20 fragments of v_mfma_f32_32x32x16_f16 = 160 VGPRs), the activation streams
+// through LDS in blocks of 32 rows (20 KB, three-slot ring filled by LDS-DMA, every HBM line fetched once), and a wave's whole
+// result for a block is 32 accumulator registers — so its epilogue (staging, residual, stores of full 128-byte lines) is over
+// in a few hundred cycles and the next block's operands are already in LDS; nothing waits for the stores, whose count is part
+// of the counted vmcnt waits.  The residual arrives by LDS-DMA as well (wave-private 32 x 64 tiles, two slots), so no register
+// holds it across the K loop.  5 waves (320 threads), one workgroup per CU, 150 KB of LDS.
+// Same arithmetic as the other back ends — same instruction and operand roles, k ascending in steps of 16, and the staged chunk
+// goes through epilogue_rows itself — so the results (and the row statistics, per 64-column part) are bit-identical to the
+// persistent kernel's except that a row has 5 statistic parts instead of 6.
+// vmcnt bookkeeping (in-order retirement; M % 32 == 0, so every store instruction is issued): per block a wave issues
+// LD = 4 (+ 4 with a residual) DMA loads at the top and ST = 4 (+ 4 with statistics) stores in its epilogue.  Top of block j:
+// the X pieces of block j were issued at the top of block j - 2, ahead of [R(j - 1)], ST(j - 2), LD(j - 1), ST(j - 1):
+// vmcnt(LD - 4 + LD + 2 ST).  Before the epilogue of block j: R(j) was the last load of the top of block j - 1, ahead of
+// ST(j - 1) and LD(j): vmcnt(ST + LD).  Blocks past the end are issued as out-of-range loads, so the counts hold to the last block.
+// The prologue (X(0), then the weights in two LDS-DMA rounds drained to vmcnt(0), then X(1) and R(0)) shortens two of the counts:
+// block 1's X wait has one block of stores behind it, block 0's R wait none.
+constexpr int WS_NST = 3;
+constexpr int WS_XST = 32 * 640;                     // bytes per X slot: 5 K slabs x [32 rows][128 B], XOR-swizzled like every slab
+constexpr int WS_R0 = WS_NST * WS_XST;               // residual slots: 2 x 5 waves x [32 rows][128 B]
+constexpr int WS_RST = 5 * 4096;
+constexpr int WS_S0 = WS_R0 + 2 * WS_RST;            // staging areas: 5 x EP_BYTES
+constexpr int WS_LDS = WS_S0 + 5 * EP_BYTES;
+static_assert(WS_LDS <= 160 * 1024, "LDS budget of the weight-stationary kernel");
+
+template <int EPI>
+__global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unused, const int nblocks) {
+    constexpr bool ADD = (EPI & EPI_ADD) != 0, STATS = (EPI & EPI_STATS) != 0;
+    constexpr int LD = ADD ? 8 : 4, ST = STATS ? 8 : 4;
+    constexpr int OOB_OFF = (int)0x80000000;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    kparams_t p = kernarg_params();
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int lrow = lane >> 3, pslot = lane & 7;
+    const unsigned lda2 = (unsigned)p->lda * 2u, ldb = (unsigned)p->ldb, ldr2 = (unsigned)p->ldr * 2u;
+
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p->A), 0, (int)p->a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(ADD ? p->residual : p->A), 0, ADD ? (int)(((unsigned)(p->M - 1) * (unsigned)p->ldr + 320u) * 2u) : 0, 0x00020000);
+    // DMA lane offsets: a piece is 8 rows x 128 B, the lane's 16-byte slot XOR-swizzled on the SOURCE side by (row >> 1) & 7
+    const int vx_e = (int)((unsigned)lrow * lda2) + (pslot ^ (lrow >> 1)) * 16;            // pieces 0, 2 (rows 0-7, 16-23)
+    const int vx_o = (int)((unsigned)lrow * lda2) + (pslot ^ (4 | (lrow >> 1))) * 16;      // pieces 1, 3
+    const int vr = (int)((unsigned)lrow * ldr2) + pslot * 16;
+
+    int nmine = 0;                                   // blocks b = blockIdx.x + i * gridDim.x
+    if ((int)blockIdx.x < nblocks) nmine = (nblocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+    if (nmine == 0) return;
+    auto issue_x = [&](const int i) {                // this wave's share of X block i: K slab `wave`, four 8-row pieces
+        const bool on = i < nmine;
+        const unsigned m0 = (unsigned)(blockIdx.x + (on ? i : 0) * gridDim.x) * 32u;
+        const int slot = (i % WS_NST) * WS_XST + wave * 4096;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            const int v = on ? ((pc & 1) ? vx_o : vx_e) : OOB_OFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(smem + slot + pc * 1024), 16, v,
+                                                     (int)((m0 + 8u * pc) * lda2 + (unsigned)wave * 128u), 0, 0);
+        }
+    };
+    auto issue_r = [&](const int i) {                // the residual of this wave's 32 x 64 outputs of block i
+        if constexpr (ADD) {
+            const bool on = i < nmine;
+            const unsigned m0 = (unsigned)(blockIdx.x + (on ? i : 0) * gridDim.x) * 32u;
+            const int slot = WS_R0 + (i & 1) * WS_RST + wave * 4096;
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcR, (lptr_t)(smem + slot + pc * 1024), 16, on ? vr : OOB_OFF,
+                                                         (int)((m0 + 8u * pc) * ldr2 + (unsigned)wave * 128u), 0, 0);
+        }
+    };
+    issue_x(0);
+
+    // The weights: rows n = 64 wave + 32 nb + l31 of B [320][ldb], 16 k per fragment (A operand: row l31, k = 8 hi ..).  Loaded straight
+    // from memory a fragment is 32 rows x 32 bytes — a quarter of every line it touches, 40 such instructions per wave: 6 of the first
+    // version's 16 us of fixed cost per launch.  So they come through LDS like every operand: the wave's 64 rows as swizzled 128-byte
+    // K slabs by LDS-DMA (full lines) into a wave-private 26-KB region behind X slot 0 (nothing else lives there yet), three slabs,
+    // then two, read back as fragments.
+    h8 wf[2][20];
+    {
+        const __amdgpu_buffer_rsrc_t rsrcB =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p->B), 0, (int)p->b_bytes, 0x00020000);
+        const unsigned ldb2 = ldb * 2u;
+        const int vw_e = (int)((unsigned)lrow * ldb2) + (pslot ^ (lrow >> 1)) * 16;
+        const int vw_o = (int)((unsigned)lrow * ldb2) + (pslot ^ (4 | (lrow >> 1))) * 16;
+        unsigned char* wreg = smem + WS_XST + wave * 26624;                   // 5 x 26 KB behind X slot 0 = 150 KB
+        const int fw = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) * 16);
+        auto w_round = [&](const int sl0, const int nsl) {
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl)
+                if (sl < nsl)
+#pragma unroll
+                    for (int pc = 0; pc < 8; ++pc)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(wreg + sl * 8192 + pc * 1024), 16, (pc & 1) ? vw_o : vw_e,
+                                                                 (int)((unsigned)(64 * wave + 8 * pc) * ldb2 + (unsigned)(sl0 + sl) * 128u), 0, 0);
+            wait_vmcnt<0>();                     // (also X(0): it was issued first)
+            __builtin_amdgcn_sched_barrier(0);   // (tools/cpu_check: the lanes of a wave meet here — on the device they are in lockstep anyway)
+        };
+        w_round(0, 3);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int t = 0; t < 12; ++t)
+                wf[nb][t] = *reinterpret_cast<const h8*>(wreg + (t >> 2) * 8192 + nb * 4096 + (fw ^ ((t & 3) * 32)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers before the region is overwritten
+        __builtin_amdgcn_sched_barrier(0);
+        w_round(3, 2);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int t = 12; t < 20; ++t)
+                wf[nb][t] = *reinterpret_cast<const h8*>(wreg + ((t >> 2) - 3) * 8192 + nb * 4096 + (fw ^ ((t & 3) * 32)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const half_t* bias = p->bias;
+    h4 cb = {};
+    if (bias != nullptr && lane < 16) cb = *reinterpret_cast<const h4*>(bias + 64 * wave + 4 * lane);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();                    // every wave has its weights: the ring, the residual slots and the staging areas are free
+    __builtin_amdgcn_sched_barrier(0);
+    issue_x(1);
+    issue_r(0);
+    float* stg = reinterpret_cast<float*>(smem + WS_S0 + wave * EP_BYTES);
+    float* cst = stg + EP_CONST;
+    if (bias != nullptr && lane < 16) {              // the wave's 64 bias values as fp32, where epilogue_rows looks for them
+        f4v bf;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bf[e] = (float)cb[e];
+        *reinterpret_cast<f4v*>(cst + 4 * lane) = bf;
+    }
+    const float alpha = p->alpha;
+    const int fa = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) * 16);
+    PreSrc ps;
+    ps.src = nullptr; ps.is_rowvec = false; ps.pitch = 0; ps.v0[0] = ps.v0[1] = 0; ps.bnd[0] = ps.bnd[1] = 0;
+    ps.mrow0 = 0; ps.ncol0 = 0; ps.Mlast = 0;
+
+    int xslot = 0;                                   // j % WS_NST
+    for (int j = 0; j < nmine; ++j) {
+        // this wave's pieces of X(j) have landed (X(0) did in the prologue; X(1) was issued behind the barrier of the prologue, with only
+        // ONE block's stores after it)
+        if (j == 1) wait_vmcnt<LD - 4 + LD + ST>();
+        else wait_vmcnt<LD - 4 + LD + 2 * ST>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                // ... everybody's have, and nobody reads X(j - 1) any more
+        __builtin_amdgcn_sched_barrier(0);
+        issue_x(j + 2);
+        issue_r(j + 1);
+        const unsigned char* xs = smem + xslot * WS_XST;
+        f16v acc0, acc1;
+        {
+            const f16v zero = {};
+            const h8 xf = *reinterpret_cast<const h8*>(xs + fa);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xf, zero, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][0], xf, zero, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 1; t < 20; ++t) {
+            const h8 xf = *reinterpret_cast<const h8*>(xs + (t >> 2) * 4096 + (fa ^ ((t & 3) * 32)));
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][t], xf, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][t], xf, acc1, 0, 0, 0);
+        }
+        // ---- epilogue of this wave's 32 x 64 block: the staged chunk of epilogue_pp (two 32-column tiles, pitch 68) ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f4v o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = acc0[4 * g + e] * alpha; o1[e] = acc1[4 * g + e] * alpha; }
+            *reinterpret_cast<f4v*>(stg + l31 * 68 + 8 * g + 4 * hi) = o0;
+            *reinterpret_cast<f4v*>(stg + l31 * 68 + 32 + 8 * g + 4 * hi) = o1;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int m0 = (int)(blockIdx.x + j * gridDim.x) * 32;
+        h8 pre[ADD ? 4 : 1];
+        if constexpr (ADD) {
+            if (j == 0) wait_vmcnt<LD>();            // R(j) has landed (wave-private: no barrier); R(0) has no stores behind it
+            else wait_vmcnt<ST + LD>();
+            const unsigned char* rs = smem + WS_R0 + (j & 1) * WS_RST + wave * 4096 + lane * 16;
+#pragma unroll
+            for (int ps_ = 0; ps_ < 4; ++ps_) pre[ps_] = *reinterpret_cast<const h8*>(rs + ps_ * 1024);
+        }
+        epilogue_rows<64, ADD ? 4 : 0, false, STATS>(p, stg, lane, m0, 64 * wave, bias != nullptr ? cst : nullptr, ps, pre, 0, 4, 1.f, 0.f,
+                                                    wave);
+        VSX_VMEM_NOTE(ST);
+        __builtin_amdgcn_sched_barrier(0);
+        xslot = xslot == WS_NST - 1 ? 0 : xslot + 1;
+    }
+}
+
+template <int EPI>
+int launch_ws_one(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws320_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
+        if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return vsx_fail(VSX_E_LAUNCH, "gemm_ws: cannot query the device");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int nblocks = (int)(p.M / 32);
+    const int grid = nblocks < n_cu ? nblocks : n_cu;
+    hipLaunchKernelGGL((gemm_ws320_kernel<EPI>), dim3((unsigned)grid), dim3(320), WS_LDS, stream, p, nblocks);
+    return vsx_check_launch("vsx_gemm_f16 (weight-stationary)");
+}
+
 }  // namespace
 
 #ifdef VSX_GEMM_TIMING
@@ -1045,6 +1263,25 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
 #undef VSX_PP_CASES
 #undef VSX_PP_CASE
     return vsx_fail(VSX_E_UNSUPPORTED, "gemm_pp: no kernel for this epilogue (pp_supported must be asked first)");
+}
+
+// Weight-stationary kernel (gemm_ws320_kernel): K = N = 320, plain row-major A, bias / residual / row statistics, whole 32-row blocks.
+bool ws_supported(const GemmParams& p) {
+    if (p.N != 320 || p.K != 320 || p.a_mode != 0 || p.geglu || p.c_mode != 0 || p.rowvec || p.rowscale || p.splitk > 1) return false;
+    if (p.M % 32 != 0 || p.M < 32 || p.M >= (1L << 26) || p.batch1 != 1) return false;
+    if (!p.vec8 || (p.residual && !p.rvec8) || !vsx_aligned16(p.bias) || !vsx_aligned16(p.A) || !vsx_aligned16(p.B)) return false;
+    if (p.lda % 8 != 0 || p.ldb % 8 != 0 || p.lda < 320 || p.ldb < 320) return false;
+    return (unsigned long)p.M * (unsigned long)p.lda * 2ul < (1ul << 31) && (!p.residual || (unsigned long)p.M * (unsigned long)p.ldr * 2ul < (1ul << 31));
+}
+
+int launch_ws(GemmParams& p, hipStream_t stream) {
+    const int epi = (p.residual ? EPI_ADD : 0) | (p.rowstats ? EPI_STATS : 0);
+    switch (epi) {
+        case 0: return launch_ws_one<0>(p, stream);
+        case EPI_ADD: return launch_ws_one<EPI_ADD>(p, stream);
+        case EPI_STATS: return launch_ws_one<EPI_STATS>(p, stream);
+        default: return launch_ws_one<EPI_ADD | EPI_STATS>(p, stream);
+    }
 }
 
 }  // namespace vsxg
