@@ -106,7 +106,7 @@ LLVM_BIN = os.environ.get('VSX_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
 # kernels whose inner loops count their own `vmcnt` entries (LDS-DMA pieces, residual ring): a scratch reload is one more
 # VMEM operation in that queue, so these must compile without spills and without a private segment (gemm_pp.hip:33-37)
 # (matched on the MANGLED names: gemm_kernelILi256E... = gemm_kernel<256, ...>)
-NO_SCRATCH = ('gemm_pp_kernel', 'flash_attn_kernel', 'gemm_kernelILi256E')
+NO_SCRATCH = ('gemm_pp_kernel', 'gemm_ws320_kernel', 'flash_attn_kernel', 'gemm_kernelILi256E')
 
 
 def parse_kernel_notes(text):
