@@ -111,7 +111,8 @@ def test_gemm_entry_point_runs_on_the_cpu(tmp_path):
     # 24 (round 6): the weight-stationary K = N = 320 kernel (gemm_ws320_kernel) — bias / residual / row statistics, bit for bit like the
     # tile kernels, with late-landing DMA: its counted waits include the stores of earlier blocks and two shortened counts in the
     # first two blocks (either one loosened by the size of its shortening fails this run)
-    for case, late in (('21', False), ('22', True), ('23', False), ('24', True)):
+    # 25: the same kernel over column slices (N = 640 / 960) with the folded LayerNorm and the gathered row vector
+    for case, late in (('21', False), ('22', True), ('23', False), ('24', True), ('25', True)):
         r = subprocess.run([exe, case], capture_output=True, text=True, timeout=900,
                            env=dict(env, CPUHIP_DMA='late') if late else env)
         print('late DMA' if late else '', r.stdout)

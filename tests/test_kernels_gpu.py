@@ -895,7 +895,7 @@ def test_weight_stationary_320_matches_the_persistent_kernel(M, res, stats):
             outs.append(y.clone())
             parts.append(getattr(y, '_vsx_rowparts', None))
     finally:
-        ops.set_option('gemm_ws', 0)
+        ops.set_option('gemm_ws', 1)
     assert torch.equal(outs[0], outs[1])
     ref = x.float() @ w.float().t() + b.float() + (r.float() if res else 0.0)
     assert float((outs[1].float() - ref).norm() / ref.norm()) < 6e-4
@@ -907,3 +907,33 @@ def test_weight_stationary_320_matches_the_persistent_kernel(M, res, stats):
         assert float((got - want).abs().max() / want.abs().max()) < 1e-5
         if parts[0] is not None:        # the persistent kernel's 6 parts of the same rounded outputs
             assert float((parts[0].sum(1) - got).abs().max() / want.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('M,N,pe', [(65536, 640, False), (65536, 960, True), (32 * 515, 960, True), (4096, 320, False)])
+def test_weight_stationary_column_slices_with_the_folded_layernorm(M, N, pe):
+    """The same kernel over column slices of 320 (N = 640 / 960, K = 320) with the LayerNorm folded into the GEMM and the temporal positional
+    row vector (gathered by LDS-DMA from the one or two vectors a 32-row block meets): bit for bit like the product's dispatch, and right
+    against the explicit LayerNorm -> Linear in fp32.  M = 32 * 515: chains of unequal length; rows_per_frame = 515 * 2: blocks that
+    straddle two vectors."""
+    from videoswap_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(N + M % 97)
+    x = (torch.randn(M, 320, device=DEV, generator=g) * 1.5 + 0.3).half()
+    gam, bet = torch.randn(320, device=DEV, generator=g).half(), torch.randn(320, device=DEV, generator=g).half()
+    w = (torch.randn(N, 320, device=DEV, generator=g) * 320 ** -0.5).half()
+    b = torch.randn(N, device=DEV, generator=g).half()
+    frames, rpf = 16, M // 16
+    pet = torch.randn(24, 320, device=DEV, generator=g).half() if pe else None
+    kw = dict(pe=pet, rows_per_frame=rpf, frames=frames) if pe else {}
+    outs = []
+    try:
+        for v in (0, 2):
+            ops.set_option('gemm_ws', v)
+            outs.append(ops.linear(ops.DeferredLN(x, gam, bet, 1e-5, **kw), w, b).clone())
+    finally:
+        ops.set_option('gemm_ws', 1)
+    assert torch.equal(outs[0], outs[1])
+    xn = F.layer_norm(x.float(), (320,), gam.float(), bet.float(), 1e-5)
+    if pe:
+        xn = xn + pet[:frames].float().repeat_interleave(rpf, 0)
+    ref = xn @ w.float().t() + b.float()
+    assert float((outs[1].float() - ref).norm() / ref.norm()) < 2e-3

@@ -469,6 +469,33 @@ int main(int argc, char** argv) {
             }
         vsx_set_option("gemm_pp", 1);
     }
+    if (only < 0 || only == nplain + 12) {
+        // the same kernel over column slices (N = 640 / 960, K = 320) with the folded LayerNorm, the positional row vector (48 rows per
+        // vector: blocks that meet two vectors) and a residual: bit for bit like the tile kernels
+        const Plain cases[] = {
+            {"weight-stationary 672x960x320 LayerNorm fold + row vector", 672, 960, 320, false, true, false, true, false, 48, 0, 0, false},
+            {"weight-stationary 672x640x320 LayerNorm fold",               672, 640, 320, false, false, false, true, false, 0, 0, 0, false},
+            {"weight-stationary 672x640x320 +res",                         672, 640, 320, true, false, false, false, false, 0, 0, 0, false},
+            {"weight-stationary 672x320x320 LayerNorm fold + row vector",  672, 320, 320, false, true, false, true, false, 32, 0, 0, false},
+        };
+        for (const Plain& c0 : cases) {
+            if (getenv("CPUHIP_QUICK") && (&c0 - cases) >= 2) continue;
+            Plain c = c0;
+            rng_state = 777u;
+            vsx_set_option("gemm_ws", 0);
+            c.pp = 0;
+            const auto a = run_plain(c, false);
+            rng_state = 777u;
+            vsx_set_option("gemm_ws", 2);
+            c.pp = 1;
+            const auto b = run_plain(c, true);
+            vsx_set_option("gemm_ws", 0);
+            const bool same = memcmp(a.data(), b.data(), a.size() * sizeof(half_t)) == 0;
+            printf("%-58s %s\n", "  ... bit-identical to the tile kernels", same ? "ok" : "FAIL");
+            n_bad += same ? 0 : 1;
+        }
+        vsx_set_option("gemm_pp", 1);
+    }
     printf(n_bad ? "%d check(s) FAILED\n" : "all checks passed\n", n_bad);
     return n_bad ? 1 : 0;
 }

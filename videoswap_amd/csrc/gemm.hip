@@ -1278,16 +1278,18 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
     const long t128 = blocks(128, 320);
     const bool pp256 = pp_ok && pp != 3 && (blocks(256, 320) >= 192 || (pp == 2 && blocks(256, 320) >= 64) || pp == 4);
     const bool pp128 = !pp256 && pp_ok && p.c_mode != 1 && ((pp >= 2 && t128 >= 32) || (pp == 1 && p.a_mode != 1 && t128 >= 240 && t128 <= 272));
-    // Weight-stationary kernel (gemm_pp.hip: gemm_ws320_kernel) for the byte-bound K = N = 320 projections of the 64 x 64 level; option
-    // "gemm_ws" / VSX_GEMM_WS: 0 = never; 1 (default) = the projections WITH a residual from 65 536 rows (8 blocks of 32 rows per CU) —
-    // where it measured at or above the persistent kernel, alone and inside the loop (profiles/r06_gemm_weight_stationary_ab.txt:
+    // Weight-stationary kernel (gemm_pp.hip: gemm_ws320_kernel) for the byte-bound K = 320 projections of the 64 x 64 level; option
+    // "gemm_ws" / VSX_GEMM_WS: 0 = never; 1 (default) = the K = N = 320 projections WITH a residual from 65 536 rows (8 blocks of 32 rows
+    // per CU) — where it measured at or above the persistent kernel, alone and inside the loop (profiles/r06_gemm_weight_stationary_ab.txt:
     // + 0.5 % frames/s at one clip per step, + 0.6 % at four; without a residual the persistent kernel's epilogue is short enough
-    // and wins); 3 = the same from 131 072 rows (A/B runs); 2 = every eligible problem (tests)
+    // and wins); 3 = the same from 131 072 rows (A/B runs); 4 = 1 + the LayerNorm-folded projections 320 -> 640 / 960 (column slices);
+    // 2 = every eligible problem (tests)
     const long ws_opt = gemm_option("gemm_ws");
-    const bool ws = ws_opt != 0 && pp != 0 && nbatch == 1 && splits <= 1 && !force_tile() && ws_supported(p) &&
-                    (ws_opt == 2 || (d->M >= (ws_opt == 3 ? 131072 : 65536) && d->residual != nullptr));
+    const bool ws_res = d->N == 320 && d->residual != nullptr && d->M >= (ws_opt == 3 ? 131072 : 65536);
+    const bool ws_ln = ws_opt == 4 && d->N > 320 && d->rowscale != nullptr && d->M >= 65536;
+    const bool ws = ws_opt != 0 && pp != 0 && nbatch == 1 && splits <= 1 && !force_tile() && ws_supported(p) && (ws_opt == 2 || ws_res || ws_ln);
     // row statistics of the output (vsx.h, ABI 8): only the staged row passes of the persistent kernels produce them
-    const long stat_parts = ws ? 5 : ((pp256 || pp128) && pp_rowstats_ok(p) ? (cols / 320) * 6 : 0);
+    const long stat_parts = ws ? (p.rowscale ? 0 : (cols / 320) * 5) : ((pp256 || pp128) && pp_rowstats_ok(p) ? (cols / 320) * 6 : 0);
     if (dry) {
         *parts_out = stat_parts;
         return VSX_OK;

@@ -994,13 +994,20 @@ constexpr int WS_XST = 32 * 640;                     // bytes per X slot: 5 K sl
 constexpr int WS_R0 = WS_NST * WS_XST;               // residual slots: 2 x 5 waves x [32 rows][128 B]
 constexpr int WS_RST = 5 * 4096;
 constexpr int WS_S0 = WS_R0 + 2 * WS_RST;            // staging areas: 5 x EP_BYTES
-constexpr int WS_LDS = WS_S0 + 5 * EP_BYTES;
+constexpr int WS_RS0 = WS_S0 + 5 * EP_BYTES;        // folded LayerNorm: (rstd, -rstd mean) of a block's 32 rows, 2 slots x 5 waves x 1 KB (256 B used)
+constexpr int WS_LDS = WS_RS0 + 2 * 5 * 1024;
 static_assert(WS_LDS <= 160 * 1024, "LDS budget of the weight-stationary kernel");
 
+// Round-6 extension: N = 320 S (S = 1 .. 3 column slices of 320, K = 320) — the LayerNorm-folded projections of the 64 x 64 level
+// (qkv 320->960 with the positional row vector, qk 320->640).  A workgroup owns ONE slice (its 320 weight rows) and a chain of row blocks;
+// the S workgroups that walk the same chain are neighbours on one XCD (workgroup b sits on XCD b % 8), start together and run at the same
+// pace, so the activation block one of them fetches from HBM is an L2 hit for the others.  EPI_LN: the (rstd, -rstd mean) pair of a lane's row is
+// an ordinary 8-byte load per block, issued one block ahead behind the DMA pieces (it is one more entry of the counted queue: LDT below);
+// EPI_ADD with a row vector: the addend tile is gathered by LDS-DMA from the one or two vectors a 32-row block meets.
 template <int EPI>
-__global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unused, const int nblocks) {
-    constexpr bool ADD = (EPI & EPI_ADD) != 0, STATS = (EPI & EPI_STATS) != 0;
-    constexpr int LD = ADD ? 8 : 4, ST = STATS ? 8 : 4;
+__global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unused, const int nblocks, const int nslices) {
+    constexpr bool ADD = (EPI & EPI_ADD) != 0, STATS = (EPI & EPI_STATS) != 0, LN = (EPI & EPI_LN) != 0;
+    constexpr int LDT = 4 + (ADD ? 4 : 0) + (LN ? 1 : 0), ST = STATS ? 8 : 4;      // VMEM loads issued at the top of a block, stores of its epilogue
     constexpr int OOB_OFF = (int)0x80000000;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     kparams_t p = kernarg_params();
@@ -1009,23 +1016,34 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int lrow = lane >> 3, pslot = lane & 7;
-    const unsigned lda2 = (unsigned)p->lda * 2u, ldb = (unsigned)p->ldb, ldr2 = (unsigned)p->ldr * 2u;
+    const unsigned lda2 = (unsigned)p->lda * 2u, ldb = (unsigned)p->ldb;
+    // (slice, chain) of this workgroup: the workgroups of XCD x are b = x + 8 * local; `nslices` neighbours share a chain
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int slice = local % nslices, grp = local / nslices;
+    const int ngroups = ((int)gridDim.x >> 3) / nslices * 8;      // the host launches a multiple of 8 * nslices workgroups
+    const int chain = grp * 8 + xcd;
+    const int ncol_s = 320 * slice;
+    const bool is_rowvec = ADD && p->residual == nullptr;
+    const unsigned ldr2 = is_rowvec ? (unsigned)p->N * 2u : (unsigned)p->ldr * 2u;
+    const unsigned rpv = is_rowvec ? (unsigned)p->rows_per_vec : 1u;
 
     const __amdgpu_buffer_rsrc_t rsrcA =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p->A), 0, (int)p->a_bytes, 0x00020000);
+    const unsigned r_rows = is_rowvec ? (unsigned)((p->M + (long)rpv - 1) / (long)rpv) : (unsigned)p->M;
     const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<half_t*>(ADD ? p->residual : p->A), 0, ADD ? (int)(((unsigned)(p->M - 1) * (unsigned)p->ldr + 320u) * 2u) : 0, 0x00020000);
+        const_cast<half_t*>(ADD ? (is_rowvec ? p->rowvec : p->residual) : p->A), 0,
+        ADD ? (int)((r_rows - 1u) * ldr2 + (unsigned)p->N * 2u) : 0, 0x00020000);
     // DMA lane offsets: a piece is 8 rows x 128 B, the lane's 16-byte slot XOR-swizzled on the SOURCE side by (row >> 1) & 7
     const int vx_e = (int)((unsigned)lrow * lda2) + (pslot ^ (lrow >> 1)) * 16;            // pieces 0, 2 (rows 0-7, 16-23)
     const int vx_o = (int)((unsigned)lrow * lda2) + (pslot ^ (4 | (lrow >> 1))) * 16;      // pieces 1, 3
     const int vr = (int)((unsigned)lrow * ldr2) + pslot * 16;
 
-    int nmine = 0;                                   // blocks b = blockIdx.x + i * gridDim.x
-    if ((int)blockIdx.x < nblocks) nmine = (nblocks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
-    if (nmine == 0) return;
+    int nmine = 0;                                   // row blocks chain + i * ngroups
+    if (grp < ngroups / 8 && chain < nblocks) nmine = (nblocks - 1 - chain) / ngroups + 1;
+    if (nmine == 0) return;                          // (whole groups leave together: no barrier is left waiting)
     auto issue_x = [&](const int i) {                // this wave's share of X block i: K slab `wave`, four 8-row pieces
         const bool on = i < nmine;
-        const unsigned m0 = (unsigned)(blockIdx.x + (on ? i : 0) * gridDim.x) * 32u;
+        const unsigned m0 = (unsigned)(chain + (on ? i : 0) * ngroups) * 32u;
         const int slot = (i % WS_NST) * WS_XST + wave * 4096;
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) {
@@ -1034,21 +1052,42 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
                                                      (int)((m0 + 8u * pc) * lda2 + (unsigned)wave * 128u), 0, 0);
         }
     };
-    auto issue_r = [&](const int i) {                // the residual of this wave's 32 x 64 outputs of block i
+    auto issue_r = [&](const int i) {                // the addend of this wave's 32 x 64 outputs of block i: residual rows, or row vectors
         if constexpr (ADD) {
             const bool on = i < nmine;
-            const unsigned m0 = (unsigned)(blockIdx.x + (on ? i : 0) * gridDim.x) * 32u;
+            const unsigned m0 = (unsigned)(chain + (on ? i : 0) * ngroups) * 32u;
             const int slot = WS_R0 + (i & 1) * WS_RST + wave * 4096;
+            const unsigned col2 = (unsigned)(ncol_s + 64 * wave) * 2u;
+            if (is_rowvec) {                         // rows_per_vec >= 32: the block meets the vector of its first row and at most the next one
+                const unsigned v0 = m0 / rpv, bnd = (v0 + 1u) * rpv;
 #pragma unroll
-            for (int pc = 0; pc < 4; ++pc)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcR, (lptr_t)(smem + slot + pc * 1024), 16, on ? vr : OOB_OFF,
-                                                         (int)((m0 + 8u * pc) * ldr2 + (unsigned)wave * 128u), 0, 0);
+                for (int pc = 0; pc < 4; ++pc) {
+                    const unsigned vec = v0 + ((m0 + 8u * pc + (unsigned)lrow) >= bnd ? 1u : 0u);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcR, (lptr_t)(smem + slot + pc * 1024), 16,
+                                                             on ? (int)(vec * ldr2) + pslot * 16 : OOB_OFF, (int)col2, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcR, (lptr_t)(smem + slot + pc * 1024), 16, on ? vr : OOB_OFF,
+                                                             (int)((m0 + 8u * pc) * ldr2 + col2), 0, 0);
+            }
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(LN ? p->rowscale : reinterpret_cast<const float*>(p->A)), 0, LN ? (int)((unsigned)p->M * 8u) : 0, 0x00020000);
+    auto issue_rs = [&](const int i) {               // EPI_LN: the (rstd, -rstd * mean) pairs of block i's 32 rows = 256 contiguous bytes, by LDS-DMA
+        if constexpr (LN) {                          // too (lanes 0-15; the others fetch zeros): a register load would make the compiler wait for everything before it
+            const bool on = i < nmine && lane < 16;
+            const unsigned m0 = (unsigned)(chain + (i < nmine ? i : 0) * ngroups) * 32u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, (lptr_t)(smem + WS_RS0 + (i & 1) * 5120 + wave * 1024), 16,
+                                                     on ? lane * 16 : OOB_OFF, (int)(m0 * 8u), 0, 0);
         }
     };
     issue_x(0);
 
-    // The weights: rows n = 64 wave + 32 nb + l31 of B [320][ldb], 16 k per fragment (A operand: row l31, k = 8 hi ..).  Loaded straight
-    // from memory a fragment is 32 rows x 32 bytes — a quarter of every line it touches, 40 such instructions per wave: 6 of the first
+    // The weights: rows n = 320 slice + 64 wave + 32 nb + l31 of B [N][ldb], 16 k per fragment (A operand: row l31, k = 8 hi ..).  Loaded
+    // straight from memory a fragment is 32 rows x 32 bytes — a quarter of every line it touches, 40 such instructions per wave: 6 of the first
     // version's 16 us of fixed cost per launch.  So they come through LDS like every operand: the wave's 64 rows as swizzled 128-byte
     // K slabs by LDS-DMA (full lines) into a wave-private 26-KB region behind X slot 0 (nothing else lives there yet), three slabs,
     // then two, read back as fragments.
@@ -1068,7 +1107,7 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
 #pragma unroll
                     for (int pc = 0; pc < 8; ++pc)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(wreg + sl * 8192 + pc * 1024), 16, (pc & 1) ? vw_o : vw_e,
-                                                                 (int)((unsigned)(64 * wave + 8 * pc) * ldb2 + (unsigned)(sl0 + sl) * 128u), 0, 0);
+                                                                 (int)((unsigned)(ncol_s + 64 * wave + 8 * pc) * ldb2 + (unsigned)(sl0 + sl) * 128u), 0, 0);
             wait_vmcnt<0>();                     // (also X(0): it was issued first)
             __builtin_amdgcn_sched_barrier(0);   // (tools/cpu_check: the lanes of a wave meet here — on the device they are in lockstep anyway)
         };
@@ -1088,21 +1127,29 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
                 wf[nb][t] = *reinterpret_cast<const h8*>(wreg + ((t >> 2) - 3) * 8192 + nb * 4096 + (fw ^ ((t & 3) * 32)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    // column constants of the wave's 64 columns: bias, and c1 = sum_k W'[n][k] of the folded LayerNorm
     const half_t* bias = p->bias;
     h4 cb = {};
-    if (bias != nullptr && lane < 16) cb = *reinterpret_cast<const h4*>(bias + 64 * wave + 4 * lane);
+    f4v cc = {};
+    if (lane < 16) {
+        if (bias != nullptr) cb = *reinterpret_cast<const h4*>(bias + ncol_s + 64 * wave + 4 * lane);
+        if constexpr (LN) cc = *reinterpret_cast<const f4v*>(p->colvec + ncol_s + 64 * wave + 4 * lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();                    // every wave has its weights: the ring, the residual slots and the staging areas are free
     __builtin_amdgcn_sched_barrier(0);
     issue_x(1);
     issue_r(0);
+    issue_rs(0);
     float* stg = reinterpret_cast<float*>(smem + WS_S0 + wave * EP_BYTES);
     float* cst = stg + EP_CONST;
-    if (bias != nullptr && lane < 16) {              // the wave's 64 bias values as fp32, where epilogue_rows looks for them
+    const bool use_cst = LN || bias != nullptr;
+    if (use_cst && lane < 16) {                      // as fp32, where epilogue_rows looks for them: [160] bias, [160] c1
         f4v bf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) bf[e] = (float)cb[e];
         *reinterpret_cast<f4v*>(cst + 4 * lane) = bf;
+        if constexpr (LN) *reinterpret_cast<f4v*>(cst + 160 + 4 * lane) = cc;
     }
     const float alpha = p->alpha;
     const int fa = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) * 16);
@@ -1114,13 +1161,14 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
     for (int j = 0; j < nmine; ++j) {
         // this wave's pieces of X(j) have landed (X(0) did in the prologue; X(1) was issued behind the barrier of the prologue, with only
         // ONE block's stores after it)
-        if (j == 1) wait_vmcnt<LD - 4 + LD + ST>();
-        else wait_vmcnt<LD - 4 + LD + 2 * ST>();
+        if (j == 1) wait_vmcnt<2 * LDT - 4 + ST>();
+        else wait_vmcnt<2 * LDT - 4 + 2 * ST>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                // ... everybody's have, and nobody reads X(j - 1) any more
         __builtin_amdgcn_sched_barrier(0);
         issue_x(j + 2);
         issue_r(j + 1);
+        issue_rs(j + 1);
         const unsigned char* xs = smem + xslot * WS_XST;
         f16v acc0, acc1;
         {
@@ -1145,17 +1193,22 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
             *reinterpret_cast<f4v*>(stg + l31 * 68 + 32 + 8 * g + 4 * hi) = o1;
         }
         __builtin_amdgcn_sched_barrier(0);
-        const int m0 = (int)(blockIdx.x + j * gridDim.x) * 32;
+        const int m0 = (chain + j * ngroups) * 32;
         h8 pre[ADD ? 4 : 1];
+        f2v rs_cur = {1.f, 0.f};
+        if constexpr (ADD || LN) {
+            if (j == 0) wait_vmcnt<LDT>();           // R(j) / the row pairs have landed (wave-private: no barrier); block 0's have no stores behind them
+            else wait_vmcnt<ST + LDT>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (ADD) {
-            if (j == 0) wait_vmcnt<LD>();            // R(j) has landed (wave-private: no barrier); R(0) has no stores behind it
-            else wait_vmcnt<ST + LD>();
             const unsigned char* rs = smem + WS_R0 + (j & 1) * WS_RST + wave * 4096 + lane * 16;
 #pragma unroll
             for (int ps_ = 0; ps_ < 4; ++ps_) pre[ps_] = *reinterpret_cast<const h8*>(rs + ps_ * 1024);
         }
-        epilogue_rows<64, ADD ? 4 : 0, false, STATS>(p, stg, lane, m0, 64 * wave, bias != nullptr ? cst : nullptr, ps, pre, 0, 4, 1.f, 0.f,
-                                                    wave);
+        if constexpr (LN) rs_cur = *reinterpret_cast<const f2v*>(smem + WS_RS0 + (j & 1) * 5120 + wave * 1024 + l31 * 8);
+        epilogue_rows<64, ADD ? 4 : 0, LN, STATS>(p, stg, lane, m0, ncol_s + 64 * wave, use_cst ? cst : nullptr, ps, pre, 0, 4, rs_cur[0],
+                                                 rs_cur[1], 5 * slice + wave);
         VSX_VMEM_NOTE(ST);
         __builtin_amdgcn_sched_barrier(0);
         xslot = xslot == WS_NST - 1 ? 0 : xslot + 1;
@@ -1179,9 +1232,14 @@ int launch_ws_one(const GemmParams& p, hipStream_t stream) {
             return vsx_fail(VSX_E_LAUNCH, "gemm_ws: cannot query the device");
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int nblocks = (int)(p.M / 32);
-    const int grid = nblocks < n_cu ? nblocks : n_cu;
-    hipLaunchKernelGGL((gemm_ws320_kernel<EPI>), dim3((unsigned)grid), dim3(320), WS_LDS, stream, p, nblocks);
+    // one workgroup per CU; the S workgroups of a chain are neighbours on one XCD (b % 8): a multiple of 8 S workgroups, no more chains than row blocks
+    const int nblocks = (int)(p.M / 32), S = (int)(p.N / 320);
+    int per_xcd = (n_cu / 8) / S;                    // chains per XCD (32 / S)
+    if (per_xcd < 1) per_xcd = 1;
+    const int want = (nblocks + 7) / 8;              // chains per XCD that have a block at all
+    if (per_xcd > want) per_xcd = want;
+    const int grid = 8 * S * per_xcd;
+    hipLaunchKernelGGL((gemm_ws320_kernel<EPI>), dim3((unsigned)grid), dim3(320), WS_LDS, stream, p, nblocks, S);
     return vsx_check_launch("vsx_gemm_f16 (weight-stationary)");
 }
 
@@ -1265,22 +1323,30 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream) {
     return vsx_fail(VSX_E_UNSUPPORTED, "gemm_pp: no kernel for this epilogue (pp_supported must be asked first)");
 }
 
-// Weight-stationary kernel (gemm_ws320_kernel): K = N = 320, plain row-major A, bias / residual / row statistics, whole 32-row blocks.
+// Weight-stationary kernel (gemm_ws320_kernel): K = 320, N = 320 / 640 / 960, plain row-major A, whole 32-row blocks; bias, residual OR row
+// vector, folded LayerNorm, row statistics (not with the LayerNorm).
 bool ws_supported(const GemmParams& p) {
-    if (p.N != 320 || p.K != 320 || p.a_mode != 0 || p.geglu || p.c_mode != 0 || p.rowvec || p.rowscale || p.splitk > 1) return false;
+    if (p.K != 320 || p.N % 320 != 0 || p.N > 960 || p.a_mode != 0 || p.geglu || p.c_mode != 0 || p.splitk > 1) return false;
+    if (p.rowvec && (p.residual || p.rows_per_vec < 32)) return false;
+    if (p.rowscale && (p.rowstats || p.colvec == nullptr || !vsx_aligned16(p.colvec))) return false;
     if (p.M % 32 != 0 || p.M < 32 || p.M >= (1L << 26) || p.batch1 != 1) return false;
-    if (!p.vec8 || (p.residual && !p.rvec8) || !vsx_aligned16(p.bias) || !vsx_aligned16(p.A) || !vsx_aligned16(p.B)) return false;
+    if (!p.vec8 || (p.residual && !p.rvec8) || !vsx_aligned16(p.bias) || !vsx_aligned16(p.rowvec) || !vsx_aligned16(p.A) || !vsx_aligned16(p.B)) return false;
     if (p.lda % 8 != 0 || p.ldb % 8 != 0 || p.lda < 320 || p.ldb < 320) return false;
     return (unsigned long)p.M * (unsigned long)p.lda * 2ul < (1ul << 31) && (!p.residual || (unsigned long)p.M * (unsigned long)p.ldr * 2ul < (1ul << 31));
 }
 
 int launch_ws(GemmParams& p, hipStream_t stream) {
-    const int epi = (p.residual ? EPI_ADD : 0) | (p.rowstats ? EPI_STATS : 0);
+    static const bool trace = getenv("VSX_WS_TRACE") != nullptr;      // (tests: which launches took this kernel)
+    if (trace) fprintf(stderr, "[vsx] weight-stationary: M=%ld N=%ld res=%d rowvec=%d ln=%d stats=%d\n", p.M, p.N, p.residual != nullptr, p.rowvec != nullptr, p.rowscale != nullptr, p.rowstats != nullptr);
+    const int epi = (p.residual || p.rowvec ? EPI_ADD : 0) | (p.rowstats ? EPI_STATS : 0) | (p.rowscale ? EPI_LN : 0);
     switch (epi) {
         case 0: return launch_ws_one<0>(p, stream);
         case EPI_ADD: return launch_ws_one<EPI_ADD>(p, stream);
         case EPI_STATS: return launch_ws_one<EPI_STATS>(p, stream);
-        default: return launch_ws_one<EPI_ADD | EPI_STATS>(p, stream);
+        case EPI_ADD | EPI_STATS: return launch_ws_one<EPI_ADD | EPI_STATS>(p, stream);
+        case EPI_LN: return launch_ws_one<EPI_LN>(p, stream);
+        case EPI_LN | EPI_ADD: return launch_ws_one<EPI_LN | EPI_ADD>(p, stream);
+        default: return vsx_fail(VSX_E_UNSUPPORTED, "gemm_ws: no kernel for this epilogue (ws_supported must be asked first)");
     }
 }
 
