@@ -128,7 +128,7 @@ typedef struct vsx_gemm_desc {
        parts into the [M][2] rowscale of the consumer (one pass over 48 bytes per row instead of vsx_row_stats' pass over
        the whole row).  Only the persistent kernel emits them (plain GEMM, N a multiple of 320, epilogue = bias and / or
        residual or row vector): ASK FIRST with vsx_gemm_rowstats_parts(d) — the number of parts this launch will write
-       (6 per 320 columns on the persistent kernel, 5 on the weight-stationary K = N = 320 kernel), 0 = it will not (keep rowstats NULL and use vsx_row_stats).  NULL / 0 = off. */
+       (6 per 320 columns on the persistent kernel, one per wave — 10, or 5 — on the weight-stationary K = 320 kernel), 0 = it will not (keep rowstats NULL and use vsx_row_stats).  NULL / 0 = off. */
     void* rowstats;
     int64_t rowstats_parts;
 } vsx_gemm_desc;

@@ -406,13 +406,13 @@ def test_row_statistics_from_the_producing_gemm(M, N, K, res):
     if M == 4096:
         assert parts is None
         return
-    ws = N == 320 and K == 320 and res and M % 32 == 0 and M >= 65536      # the weight-stationary kernel (round 6): a part per wave = 64 columns
-    assert parts is not None and parts.shape == (M, 5 if ws else (N // 320) * 6, 2)
+    ws = N == 320 and K == 320 and res and M % 32 == 0 and M >= 65536      # the weight-stationary kernel (round 6): a part per wave = 32 columns
+    assert parts is not None and parts.shape == (M, 10 if ws else (N // 320) * 6, 2)
     cols = []
     for h in range(N // 160):
         cols += [(h * 160, 64), (h * 160 + 64, 64), (h * 160 + 128, 32)]
     if ws:
-        cols = [(64 * i, 64) for i in range(5)]
+        cols = [(32 * i, 32) for i in range(10)]
     yf = y.float()
     want = torch.stack([torch.stack([yf[:, c0:c0 + wd].sum(1), (yf[:, c0:c0 + wd] ** 2).sum(1)], -1) for c0, wd in cols], 1)
     assert (parts - want).abs().max() <= 1e-3 * (1 + want.abs().max())
@@ -873,15 +873,17 @@ def test_errors_are_reported():
         ops().linear(x.cpu(), w.cpu())
 
 
+@pytest.mark.parametrize('waves', [10, 5])
 @pytest.mark.parametrize('M', [131072, 32 * 1027, 96])
 @pytest.mark.parametrize('res,stats', [(False, False), (True, False), (False, True), (True, True)])
-def test_weight_stationary_320_matches_the_persistent_kernel(M, res, stats):
+def test_weight_stationary_320_matches_the_persistent_kernel(M, res, stats, waves):
     """gemm_ws320_kernel (csrc/gemm_pp.hip; option gemm_ws): the K = N = 320 projections of the 64 x 64 level with the weights in
     registers and the activation streamed in 32-row blocks.  Same instruction, operand roles and k order as the other back ends and
     the same staged row passes, so the output must agree BIT FOR BIT with the product's dispatch (and with fp32 to fp16 rounding);
-    its row statistics come in 5 parts per row instead of 6 and must add up to the same sums.  M = 32 * 1027: workgroups with 5 and 4
-    blocks (the out-of-range tail pieces); M = 96: fewer blocks than CUs."""
+    its row statistics come in one part per wave (option ws_waves: 10 waves of 32 columns, or 5 of 64) instead of 6 and must add up to the
+    same sums.  M = 32 * 1027: workgroups with 5 and 4 blocks (the out-of-range tail pieces); M = 96: fewer blocks than CUs."""
     from videoswap_amd import ops
+    ops.set_option('ws_waves', waves)
     g = torch.Generator(device=DEV).manual_seed(M % 1000 + 2 * res + stats)
     x = torch.randn(M, 320, device=DEV, generator=g).half()
     w = (torch.randn(320, 320, device=DEV, generator=g) * 320 ** -0.5).half()
@@ -896,11 +898,12 @@ def test_weight_stationary_320_matches_the_persistent_kernel(M, res, stats):
             parts.append(getattr(y, '_vsx_rowparts', None))
     finally:
         ops.set_option('gemm_ws', 1)
+        ops.set_option('ws_waves', 10)
     assert torch.equal(outs[0], outs[1])
     ref = x.float() @ w.float().t() + b.float() + (r.float() if res else 0.0)
     assert float((outs[1].float() - ref).norm() / ref.norm()) < 6e-4
     if stats:
-        assert parts[1] is not None and parts[1].shape == (M, 5, 2)
+        assert parts[1] is not None and parts[1].shape == (M, waves, 2)
         y = outs[1].float()
         want = torch.stack([y.sum(1), (y * y).sum(1)], 1)
         got = parts[1].sum(1)
@@ -909,8 +912,9 @@ def test_weight_stationary_320_matches_the_persistent_kernel(M, res, stats):
             assert float((parts[0].sum(1) - got).abs().max() / want.abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize('waves', [10, 5])
 @pytest.mark.parametrize('M,N,pe', [(65536, 640, False), (65536, 960, True), (32 * 515, 960, True), (4096, 320, False)])
-def test_weight_stationary_column_slices_with_the_folded_layernorm(M, N, pe):
+def test_weight_stationary_column_slices_with_the_folded_layernorm(M, N, pe, waves):
     """The same kernel over column slices of 320 (N = 640 / 960, K = 320) with the LayerNorm folded into the GEMM and the temporal positional
     row vector (gathered by LDS-DMA from the one or two vectors a 32-row block meets): bit for bit like the product's dispatch, and right
     against the explicit LayerNorm -> Linear in fp32.  M = 32 * 515: chains of unequal length; rows_per_frame = 515 * 2: blocks that
@@ -925,12 +929,14 @@ def test_weight_stationary_column_slices_with_the_folded_layernorm(M, N, pe):
     pet = torch.randn(24, 320, device=DEV, generator=g).half() if pe else None
     kw = dict(pe=pet, rows_per_frame=rpf, frames=frames) if pe else {}
     outs = []
+    ops.set_option('ws_waves', waves)
     try:
         for v in (0, 2):
             ops.set_option('gemm_ws', v)
             outs.append(ops.linear(ops.DeferredLN(x, gam, bet, 1e-5, **kw), w, b).clone())
     finally:
         ops.set_option('gemm_ws', 1)
+        ops.set_option('ws_waves', 10)
     assert torch.equal(outs[0], outs[1])
     xn = F.layer_norm(x.float(), (320,), gam.float(), bet.float(), 1e-5)
     if pe:

@@ -426,7 +426,8 @@ int main(int argc, char** argv) {
                 rng_state = 4242u + res;
                 auto A = randh((size_t)M * K), B = randh((size_t)N * K, 1.0f / sqrtf((float)K)), bias = randh(N), R = randh((size_t)M * N);
                 std::vector<half_t> C0((size_t)M * N, (half_t)-7.f), C1((size_t)M * N, (half_t)-7.f);
-                std::vector<float> stats((size_t)M * 5 * 2, -1.f);
+                const long NP = (getenv("VSX_WS_WAVES") && atoi(getenv("VSX_WS_WAVES")) == 5) ? 5 : 10;       // statistic parts per row = waves per workgroup
+                std::vector<float> stats((size_t)M * NP * 2, -1.f);
                 vsx_gemm_desc d{};
                 d.M = M; d.N = N; d.K = K; d.batch0 = d.batch1 = 1;
                 d.A = A.data(); d.lda = K; d.B = B.data(); d.ldb = K; d.ldc = N; d.bias = bias.data();
@@ -441,8 +442,8 @@ int main(int argc, char** argv) {
                 vsx_set_option("gemm_ws", 2);
                 if (st) {
                     const long parts = vsx_gemm_rowstats_parts(&d);
-                    if (parts != 5) { printf("%-58s rowstats parts %ld (want 5) FAIL\n", name, parts); ++n_bad; }
-                    d.rowstats = stats.data(); d.rowstats_parts = 5;
+                    if (parts != NP) { printf("%-58s rowstats parts %ld (want %ld) FAIL\n", name, parts, NP); ++n_bad; }
+                    d.rowstats = stats.data(); d.rowstats_parts = NP;
                 }
                 const int rc1 = vsx_gemm_f16(&d, nullptr);
                 vsx_set_option("gemm_ws", 0);
@@ -451,7 +452,7 @@ int main(int argc, char** argv) {
                 if (st)
                     for (long m = 0; m < M; ++m) {
                         double s1 = 0, s2 = 0, w1 = 0, w2 = 0;
-                        for (int part = 0; part < 5; ++part) { s1 += stats[(m * 5 + part) * 2]; s2 += stats[(m * 5 + part) * 2 + 1]; }
+                        for (int part = 0; part < NP; ++part) { s1 += stats[(m * NP + part) * 2]; s2 += stats[(m * NP + part) * 2 + 1]; }
                         for (long n = 0; n < N; ++n) { const double v = (double)C1[m * N + n]; w1 += v; w2 += v * v; }
                         worst = fmax(worst, fmax(fabs(s1 - w1) / (1.0 + fabs(w1)), fabs(s2 - w2) / (1.0 + fabs(w2))));
                     }

@@ -29,7 +29,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--reps', type=int, default=6)
+    ap.add_argument('--waves', type=int, default=10, help='option ws_waves: 10 waves of 32 columns or 5 of 64')
     args = ap.parse_args()
+    ops.set_option('ws_waves', args.waves)
+    print(f'# ws_waves = {args.waves}')
     print(f'# K = N = 320 projections, median of {args.rounds} interleaved rounds x {args.reps} launches; us per launch; GB/s of the algorithmic bytes (A + C [+ residual])')
     print(f'{"shape":44s} {"persistent":>11s} {"weight-st.":>11s} {"ratio":>6s} {"GB/s":>7s} {"GB/s":>7s}  outputs')
     g = torch.Generator(device=DEV).manual_seed(1)
@@ -97,6 +100,7 @@ def main():
                   flush=True)
         del x
     ops.set_option('gemm_ws', 1)
+    ops.set_option('ws_waves', 10)
 
 
 if __name__ == '__main__':

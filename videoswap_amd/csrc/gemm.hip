@@ -1055,7 +1055,7 @@ Option g_options[] = {{"gemm_pp", "VSX_GEMM_PP", 1, false}, {"pp_sched", "VSX_PP
                       {"tile_tune", "VSX_TUNE_TILE", 0, false}, {"xcd_walk", "VSX_XCD_WALK", 1, false},
                       {"attn_qb", "VSX_ATTN_QB", 0, false}, {"temporal_out", "VSX_TEMPORAL_OUT", 0, false},
                       {"attn_o16", "VSX_ATTN_O16", 0, false}, {"gn_fuse", "VSX_GN_FUSE", 0, false},
-                      {"gemm_ws", "VSX_GEMM_WS", 1, false}};
+                      {"gemm_ws", "VSX_GEMM_WS", 1, false}, {"ws_waves", "VSX_WS_WAVES", 10, false}};
 Option* find_option(const char* name) {
     for (auto& o : g_options)
         if (strcmp(o.name, name) == 0) {
@@ -1287,9 +1287,10 @@ static int gemm_impl(const vsx_gemm_desc* d, vsx_stream_t stream_, const bool dr
     const long ws_opt = gemm_option("gemm_ws");
     const bool ws_res = d->N == 320 && d->residual != nullptr && d->M >= (ws_opt == 3 ? 131072 : 65536);
     const bool ws_ln = ws_opt == 4 && d->N > 320 && d->rowscale != nullptr && d->M >= 65536;
-    const bool ws = ws_opt != 0 && pp != 0 && nbatch == 1 && splits <= 1 && !force_tile() && ws_supported(p) && (ws_opt == 2 || ws_res || ws_ln);
+    const bool ws_st = ws_opt == 5 && d->N == 320 && d->rowstats_parts >= 0 && d->rowscale == nullptr && d->residual == nullptr && d->M >= 131072;     // (5: + the residual-free K = N = 320 launches, A/B runs)
+    const bool ws = ws_opt != 0 && pp != 0 && nbatch == 1 && splits <= 1 && !force_tile() && ws_supported(p) && (ws_opt == 2 || ws_res || ws_ln || ws_st);
     // row statistics of the output (vsx.h, ABI 8): only the staged row passes of the persistent kernels produce them
-    const long stat_parts = ws ? (p.rowscale ? 0 : (cols / 320) * 5) : ((pp256 || pp128) && pp_rowstats_ok(p) ? (cols / 320) * 6 : 0);
+    const long stat_parts = ws ? (p.rowscale ? 0 : (cols / 320) * ws_waves()) : ((pp256 || pp128) && pp_rowstats_ok(p) ? (cols / 320) * 6 : 0);
     if (dry) {
         *parts_out = stat_parts;
         return VSX_OK;

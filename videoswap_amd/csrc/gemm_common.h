@@ -97,5 +97,6 @@ int launch_pp(GemmParams& p, int bm, hipStream_t stream);
 // gemm_pp.hip: weight-stationary kernel for the byte-bound K = N = 320 projections (32-row blocks streamed past register-resident weights)
 bool ws_supported(const GemmParams& p);
 int launch_ws(GemmParams& p, hipStream_t stream);
+int ws_waves();                              // 5 or 10: waves per workgroup = row-statistics parts per 320 columns
 
 }  // namespace vsxg

@@ -989,25 +989,33 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
 // ST(j - 1) and LD(j): vmcnt(ST + LD).  Blocks past the end are issued as out-of-range loads, so the counts hold to the last block.
 // The prologue (X(0), then the weights in two LDS-DMA rounds drained to vmcnt(0), then X(1) and R(0)) shortens two of the counts:
 // block 1's X wait has one block of stores behind it, block 0's R wait none.
+// NW waves per workgroup (round 6, second form): 5 waves of 64 columns, or 10 waves of 32 columns — half the registers per wave (80 of weight
+// fragments), 2 - 3 waves per SIMD instead of 1 - 2, so that one wave's barrier, fragment reads and epilogue hide under another's MFMAs (with 5
+// waves a block costs ~3 us whatever its bytes: only the residual's traffic hid that).
 constexpr int WS_NST = 3;
 constexpr int WS_XST = 32 * 640;                     // bytes per X slot: 5 K slabs x [32 rows][128 B], XOR-swizzled like every slab
-constexpr int WS_R0 = WS_NST * WS_XST;               // residual slots: 2 x 5 waves x [32 rows][128 B]
-constexpr int WS_RST = 5 * 4096;
-constexpr int WS_S0 = WS_R0 + 2 * WS_RST;            // staging areas: 5 x EP_BYTES
-constexpr int WS_RS0 = WS_S0 + 5 * EP_BYTES;        // folded LayerNorm: (rstd, -rstd mean) of a block's 32 rows, 2 slots x 5 waves x 1 KB (256 B used)
-constexpr int WS_LDS = WS_RS0 + 2 * 5 * 1024;
-static_assert(WS_LDS <= 160 * 1024, "LDS budget of the weight-stationary kernel");
+constexpr int WS_R0 = WS_NST * WS_XST;               // addend slots: 2 x [the waves' 32-row tiles of their columns] = 2 x 20 KB
+constexpr int WS_RST = 32 * 640;
+constexpr int WS_S0 = WS_R0 + 2 * WS_RST;            // staging areas: NW x WsGeo<NW>::EPW, then the row pairs of a folded LayerNorm (2 slots x 1 KB, 256 B used)
+template <int NW>
+struct WsGeo {
+    static constexpr int COLS = 320 / NW, NB = COLS / 32, LPR = COLS / 8, RPP = 64 / LPR, PASSES = 32 / RPP;
+    static constexpr int PITCH = NB * 32 + 4;                          // floats per staged row
+    static constexpr int SCST = NW == 5 ? EP_CONST : 32 * PITCH;       // float offset of the column constants behind the staged chunk
+    static constexpr int EPW = NW == 5 ? EP_BYTES : (SCST + 160 + COLS) * 4;
+    static constexpr int RS0 = WS_S0 + NW * EPW;
+    static constexpr int LDS = RS0 + 2 * 1024;
+    static constexpr int WREG = 3 * COLS * 128;                        // prologue: three K slabs of the wave's weight rows
+    static_assert(LDS <= 160 * 1024 && WS_XST + NW * WREG <= LDS, "LDS budget of the weight-stationary kernel");
+};
 
-// Round-6 extension: N = 320 S (S = 1 .. 3 column slices of 320, K = 320) — the LayerNorm-folded projections of the 64 x 64 level
-// (qkv 320->960 with the positional row vector, qk 320->640).  A workgroup owns ONE slice (its 320 weight rows) and a chain of row blocks;
-// the S workgroups that walk the same chain are neighbours on one XCD (workgroup b sits on XCD b % 8), start together and run at the same
-// pace, so the activation block one of them fetches from HBM is an L2 hit for the others.  EPI_LN: the (rstd, -rstd mean) pair of a lane's row is
-// an ordinary 8-byte load per block, issued one block ahead behind the DMA pieces (it is one more entry of the counted queue: LDT below);
-// EPI_ADD with a row vector: the addend tile is gathered by LDS-DMA from the one or two vectors a 32-row block meets.
-template <int EPI>
-__global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unused, const int nblocks, const int nslices) {
+template <int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_ws320_kernel(const GemmParams p_unused, const int nblocks, const int nslices) {
+    typedef WsGeo<NW> G_;
+    constexpr int COLS = G_::COLS, NB = G_::NB, LPR = G_::LPR, RPP = G_::RPP, PASSES = G_::PASSES, XP = 20 / NW;
     constexpr bool ADD = (EPI & EPI_ADD) != 0, STATS = (EPI & EPI_STATS) != 0, LN = (EPI & EPI_LN) != 0;
-    constexpr int LDT = 4 + (ADD ? 4 : 0) + (LN ? 1 : 0), ST = STATS ? 8 : 4;      // VMEM loads issued at the top of a block, stores of its epilogue
+    // VMEM loads issued at the top of a block (X pieces, addend pieces, the row pairs), stores of its epilogue
+    constexpr int LDT = XP + (ADD ? PASSES : 0) + (LN ? 1 : 0), ST = STATS ? 2 * PASSES : PASSES;
     constexpr int OOB_OFF = (int)0x80000000;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     kparams_t p = kernarg_params();
@@ -1036,41 +1044,43 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
     // DMA lane offsets: a piece is 8 rows x 128 B, the lane's 16-byte slot XOR-swizzled on the SOURCE side by (row >> 1) & 7
     const int vx_e = (int)((unsigned)lrow * lda2) + (pslot ^ (lrow >> 1)) * 16;            // pieces 0, 2 (rows 0-7, 16-23)
     const int vx_o = (int)((unsigned)lrow * lda2) + (pslot ^ (4 | (lrow >> 1))) * 16;      // pieces 1, 3
-    const int vr = (int)((unsigned)lrow * ldr2) + pslot * 16;
+    const int rrow = lane / LPR, rslot = lane % LPR;                      // addend piece: RPP rows x (COLS halfs = LPR 16-byte slots)
+    const int vr = (int)((unsigned)rrow * ldr2) + rslot * 16;
 
     int nmine = 0;                                   // row blocks chain + i * ngroups
     if (grp < ngroups / 8 && chain < nblocks) nmine = (nblocks - 1 - chain) / ngroups + 1;
     if (nmine == 0) return;                          // (whole groups leave together: no barrier is left waiting)
-    auto issue_x = [&](const int i) {                // this wave's share of X block i: K slab `wave`, four 8-row pieces
+    auto issue_x = [&](const int i) {                // this wave's share of X block i: XP of the 20 pieces (K slab q / 4, rows 8 (q % 4) ..)
         const bool on = i < nmine;
         const unsigned m0 = (unsigned)(chain + (on ? i : 0) * ngroups) * 32u;
-        const int slot = (i % WS_NST) * WS_XST + wave * 4096;
+        const int slot = (i % WS_NST) * WS_XST;
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) {
-            const int v = on ? ((pc & 1) ? vx_o : vx_e) : OOB_OFF;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(smem + slot + pc * 1024), 16, v,
-                                                     (int)((m0 + 8u * pc) * lda2 + (unsigned)wave * 128u), 0, 0);
+        for (int k = 0; k < XP; ++k) {
+            const int q = wave * XP + k, sl = q >> 2, pc = q & 3;          // (XP is 4 or 2: pc & 1 == k & 1)
+            const int v = on ? ((k & 1) ? vx_o : vx_e) : OOB_OFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lptr_t)(smem + slot + sl * 4096 + pc * 1024), 16, v,
+                                                     (int)((m0 + 8u * pc) * lda2 + (unsigned)sl * 128u), 0, 0);
         }
     };
-    auto issue_r = [&](const int i) {                // the addend of this wave's 32 x 64 outputs of block i: residual rows, or row vectors
+    auto issue_r = [&](const int i) {                // the addend of this wave's 32 x COLS outputs of block i: residual rows, or row vectors
         if constexpr (ADD) {
             const bool on = i < nmine;
             const unsigned m0 = (unsigned)(chain + (on ? i : 0) * ngroups) * 32u;
-            const int slot = WS_R0 + (i & 1) * WS_RST + wave * 4096;
-            const unsigned col2 = (unsigned)(ncol_s + 64 * wave) * 2u;
+            const int slot = WS_R0 + (i & 1) * WS_RST + wave * (PASSES * 1024);
+            const unsigned col2 = (unsigned)(ncol_s + COLS * wave) * 2u;
             if (is_rowvec) {                         // rows_per_vec >= 32: the block meets the vector of its first row and at most the next one
                 const unsigned v0 = m0 / rpv, bnd = (v0 + 1u) * rpv;
 #pragma unroll
-                for (int pc = 0; pc < 4; ++pc) {
-                    const unsigned vec = v0 + ((m0 + 8u * pc + (unsigned)lrow) >= bnd ? 1u : 0u);
+                for (int pc = 0; pc < PASSES; ++pc) {
+                    const unsigned vec = v0 + ((m0 + (unsigned)(RPP * pc + rrow)) >= bnd ? 1u : 0u);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcR, (lptr_t)(smem + slot + pc * 1024), 16,
-                                                             on ? (int)(vec * ldr2) + pslot * 16 : OOB_OFF, (int)col2, 0, 0);
+                                                             on ? (int)(vec * ldr2) + rslot * 16 : OOB_OFF, (int)col2, 0, 0);
                 }
             } else {
 #pragma unroll
-                for (int pc = 0; pc < 4; ++pc)
+                for (int pc = 0; pc < PASSES; ++pc)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcR, (lptr_t)(smem + slot + pc * 1024), 16, on ? vr : OOB_OFF,
-                                                             (int)((m0 + 8u * pc) * ldr2 + col2), 0, 0);
+                                                             (int)((m0 + (unsigned)(RPP * pc)) * ldr2 + col2), 0, 0);
             }
         }
     };
@@ -1080,7 +1090,7 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
         if constexpr (LN) {                          // too (lanes 0-15; the others fetch zeros): a register load would make the compiler wait for everything before it
             const bool on = i < nmine && lane < 16;
             const unsigned m0 = (unsigned)(chain + (i < nmine ? i : 0) * ngroups) * 32u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, (lptr_t)(smem + WS_RS0 + (i & 1) * 5120 + wave * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcS, (lptr_t)(smem + G_::RS0 + (i & 1) * 1024), 16,        // (every wave fetches the same 256 bytes into the same place: its own vmcnt covers its own copy)
                                                      on ? lane * 16 : OOB_OFF, (int)(m0 * 8u), 0, 0);
         }
     };
@@ -1091,60 +1101,60 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
     // version's 16 us of fixed cost per launch.  So they come through LDS like every operand: the wave's 64 rows as swizzled 128-byte
     // K slabs by LDS-DMA (full lines) into a wave-private 26-KB region behind X slot 0 (nothing else lives there yet), three slabs,
     // then two, read back as fragments.
-    h8 wf[2][20];
+    h8 wf[NB][20];
     {
         const __amdgpu_buffer_rsrc_t rsrcB =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p->B), 0, (int)p->b_bytes, 0x00020000);
         const unsigned ldb2 = ldb * 2u;
         const int vw_e = (int)((unsigned)lrow * ldb2) + (pslot ^ (lrow >> 1)) * 16;
         const int vw_o = (int)((unsigned)lrow * ldb2) + (pslot ^ (4 | (lrow >> 1))) * 16;
-        unsigned char* wreg = smem + WS_XST + wave * 26624;                   // 5 x 26 KB behind X slot 0 = 150 KB
+        unsigned char* wreg = smem + WS_XST + wave * G_::WREG;                // NW regions of three slabs behind X slot 0
         const int fw = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) * 16);
         auto w_round = [&](const int sl0, const int nsl) {
 #pragma unroll
             for (int sl = 0; sl < 3; ++sl)
                 if (sl < nsl)
 #pragma unroll
-                    for (int pc = 0; pc < 8; ++pc)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(wreg + sl * 8192 + pc * 1024), 16, (pc & 1) ? vw_o : vw_e,
-                                                                 (int)((unsigned)(ncol_s + 64 * wave + 8 * pc) * ldb2 + (unsigned)(sl0 + sl) * 128u), 0, 0);
+                    for (int pc = 0; pc < COLS / 8; ++pc)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lptr_t)(wreg + sl * (COLS * 128) + pc * 1024), 16, (pc & 1) ? vw_o : vw_e,
+                                                                 (int)((unsigned)(ncol_s + COLS * wave + 8 * pc) * ldb2 + (unsigned)(sl0 + sl) * 128u), 0, 0);
             wait_vmcnt<0>();                     // (also X(0): it was issued first)
             __builtin_amdgcn_sched_barrier(0);   // (tools/cpu_check: the lanes of a wave meet here — on the device they are in lockstep anyway)
         };
         w_round(0, 3);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int t = 0; t < 12; ++t)
-                wf[nb][t] = *reinterpret_cast<const h8*>(wreg + (t >> 2) * 8192 + nb * 4096 + (fw ^ ((t & 3) * 32)));
+                wf[nb][t] = *reinterpret_cast<const h8*>(wreg + (t >> 2) * (COLS * 128) + nb * 4096 + (fw ^ ((t & 3) * 32)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers before the region is overwritten
         __builtin_amdgcn_sched_barrier(0);
         w_round(3, 2);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int t = 12; t < 20; ++t)
-                wf[nb][t] = *reinterpret_cast<const h8*>(wreg + ((t >> 2) - 3) * 8192 + nb * 4096 + (fw ^ ((t & 3) * 32)));
+                wf[nb][t] = *reinterpret_cast<const h8*>(wreg + ((t >> 2) - 3) * (COLS * 128) + nb * 4096 + (fw ^ ((t & 3) * 32)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    // column constants of the wave's 64 columns: bias, and c1 = sum_k W'[n][k] of the folded LayerNorm
+    // column constants of the wave's COLS columns: bias, and c1 = sum_k W'[n][k] of the folded LayerNorm
     const half_t* bias = p->bias;
     h4 cb = {};
     f4v cc = {};
-    if (lane < 16) {
-        if (bias != nullptr) cb = *reinterpret_cast<const h4*>(bias + ncol_s + 64 * wave + 4 * lane);
-        if constexpr (LN) cc = *reinterpret_cast<const f4v*>(p->colvec + ncol_s + 64 * wave + 4 * lane);
+    if (lane < COLS / 4) {
+        if (bias != nullptr) cb = *reinterpret_cast<const h4*>(bias + ncol_s + COLS * wave + 4 * lane);
+        if constexpr (LN) cc = *reinterpret_cast<const f4v*>(p->colvec + ncol_s + COLS * wave + 4 * lane);
     }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                    // every wave has its weights: the ring, the residual slots and the staging areas are free
+    __builtin_amdgcn_s_barrier();                    // every wave has its weights: the ring, the addend slots and the staging areas are free
     __builtin_amdgcn_sched_barrier(0);
     issue_x(1);
     issue_r(0);
     issue_rs(0);
-    float* stg = reinterpret_cast<float*>(smem + WS_S0 + wave * EP_BYTES);
-    float* cst = stg + EP_CONST;
+    float* stg = reinterpret_cast<float*>(smem + WS_S0 + wave * G_::EPW);
+    float* cst = stg + G_::SCST;
     const bool use_cst = LN || bias != nullptr;
-    if (use_cst && lane < 16) {                      // as fp32, where epilogue_rows looks for them: [160] bias, [160] c1
+    if (use_cst && lane < COLS / 4) {                // as fp32, where epilogue_rows looks for them: bias at [0 ..), c1 at [160 ..)
         f4v bf;
 #pragma unroll
         for (int e = 0; e < 4; ++e) bf[e] = (float)cb[e];
@@ -1170,31 +1180,32 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
         issue_r(j + 1);
         issue_rs(j + 1);
         const unsigned char* xs = smem + xslot * WS_XST;
-        f16v acc0, acc1;
+        f16v acc[NB];
         {
             const f16v zero = {};
             const h8 xf = *reinterpret_cast<const h8*>(xs + fa);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][0], xf, zero, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][0], xf, zero, 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nb][0], xf, zero, 0, 0, 0);
         }
 #pragma unroll
         for (int t = 1; t < 20; ++t) {
             const h8 xf = *reinterpret_cast<const h8*>(xs + (t >> 2) * 4096 + (fa ^ ((t & 3) * 32)));
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][t], xf, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][t], xf, acc1, 0, 0, 0);
-        }
-        // ---- epilogue of this wave's 32 x 64 block: the staged chunk of epilogue_pp (two 32-column tiles, pitch 68) ----
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f4v o0, o1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { o0[e] = acc0[4 * g + e] * alpha; o1[e] = acc1[4 * g + e] * alpha; }
-            *reinterpret_cast<f4v*>(stg + l31 * 68 + 8 * g + 4 * hi) = o0;
-            *reinterpret_cast<f4v*>(stg + l31 * 68 + 32 + 8 * g + 4 * hi) = o1;
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[nb][t], xf, acc[nb], 0, 0, 0);
         }
+        // ---- epilogue of this wave's 32 x COLS block: the staged chunk of epilogue_pp (NB 32-column tiles, pitch 32 NB + 4) ----
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f4v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = acc[nb][4 * g + e] * alpha;
+                *reinterpret_cast<f4v*>(stg + l31 * G_::PITCH + nb * 32 + 8 * g + 4 * hi) = o;
+            }
         __builtin_amdgcn_sched_barrier(0);
         const int m0 = (chain + j * ngroups) * 32;
-        h8 pre[ADD ? 4 : 1];
+        h8 pre[ADD ? PASSES : 1];
         f2v rs_cur = {1.f, 0.f};
         if constexpr (ADD || LN) {
             if (j == 0) wait_vmcnt<LDT>();           // R(j) / the row pairs have landed (wave-private: no barrier); block 0's have no stores behind them
@@ -1202,25 +1213,25 @@ __global__ __launch_bounds__(320) void gemm_ws320_kernel(const GemmParams p_unus
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (ADD) {
-            const unsigned char* rs = smem + WS_R0 + (j & 1) * WS_RST + wave * 4096 + lane * 16;
+            const unsigned char* rs = smem + WS_R0 + (j & 1) * WS_RST + wave * (PASSES * 1024) + lane * 16;
 #pragma unroll
-            for (int ps_ = 0; ps_ < 4; ++ps_) pre[ps_] = *reinterpret_cast<const h8*>(rs + ps_ * 1024);
+            for (int ps_ = 0; ps_ < PASSES; ++ps_) pre[ps_] = *reinterpret_cast<const h8*>(rs + ps_ * 1024);
         }
-        if constexpr (LN) rs_cur = *reinterpret_cast<const f2v*>(smem + WS_RS0 + (j & 1) * 5120 + wave * 1024 + l31 * 8);
-        epilogue_rows<64, ADD ? 4 : 0, LN, STATS>(p, stg, lane, m0, ncol_s + 64 * wave, use_cst ? cst : nullptr, ps, pre, 0, 4, rs_cur[0],
-                                                 rs_cur[1], 5 * slice + wave);
+        if constexpr (LN) rs_cur = *reinterpret_cast<const f2v*>(smem + G_::RS0 + (j & 1) * 1024 + l31 * 8);
+        epilogue_rows<COLS, ADD ? PASSES : 0, LN, STATS>(p, stg, lane, m0, ncol_s + COLS * wave, use_cst ? cst : nullptr, ps, pre, 0, PASSES,
+                                                        rs_cur[0], rs_cur[1], NW * slice + wave);
         VSX_VMEM_NOTE(ST);
         __builtin_amdgcn_sched_barrier(0);
         xslot = xslot == WS_NST - 1 ? 0 : xslot + 1;
     }
 }
 
-template <int EPI>
+template <int EPI, int NW>
 int launch_ws_one(const GemmParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws320_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ws320_kernel<EPI, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WsGeo<NW>::LDS);
         if (e != hipSuccess) return vsx_fail(VSX_E_LAUNCH, "gemm_ws: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
@@ -1239,7 +1250,7 @@ int launch_ws_one(const GemmParams& p, hipStream_t stream) {
     const int want = (nblocks + 7) / 8;              // chains per XCD that have a block at all
     if (per_xcd > want) per_xcd = want;
     const int grid = 8 * S * per_xcd;
-    hipLaunchKernelGGL((gemm_ws320_kernel<EPI>), dim3((unsigned)grid), dim3(320), WS_LDS, stream, p, nblocks, S);
+    hipLaunchKernelGGL((gemm_ws320_kernel<EPI, NW>), dim3((unsigned)grid), dim3(NW * 64), WsGeo<NW>::LDS, stream, p, nblocks, S);
     return vsx_check_launch("vsx_gemm_f16 (weight-stationary)");
 }
 
@@ -1335,19 +1346,25 @@ bool ws_supported(const GemmParams& p) {
     return (unsigned long)p.M * (unsigned long)p.lda * 2ul < (1ul << 31) && (!p.residual || (unsigned long)p.M * (unsigned long)p.ldr * 2ul < (1ul << 31));
 }
 
+// option "ws_waves" / VSX_WS_WAVES: 5 waves of 64 columns or 10 waves of 32 (the row statistics then come in 10 parts per 320 columns)
+int ws_waves() { return gemm_option("ws_waves") == 5 ? 5 : 10; }
+
 int launch_ws(GemmParams& p, hipStream_t stream) {
     static const bool trace = getenv("VSX_WS_TRACE") != nullptr;      // (tests: which launches took this kernel)
     if (trace) fprintf(stderr, "[vsx] weight-stationary: M=%ld N=%ld res=%d rowvec=%d ln=%d stats=%d\n", p.M, p.N, p.residual != nullptr, p.rowvec != nullptr, p.rowscale != nullptr, p.rowstats != nullptr);
     const int epi = (p.residual || p.rowvec ? EPI_ADD : 0) | (p.rowstats ? EPI_STATS : 0) | (p.rowscale ? EPI_LN : 0);
+    const bool w10 = ws_waves() == 10;
+#define VSX_WS_CASE(E) case (E): return w10 ? launch_ws_one<(E), 10>(p, stream) : launch_ws_one<(E), 5>(p, stream);
     switch (epi) {
-        case 0: return launch_ws_one<0>(p, stream);
-        case EPI_ADD: return launch_ws_one<EPI_ADD>(p, stream);
-        case EPI_STATS: return launch_ws_one<EPI_STATS>(p, stream);
-        case EPI_ADD | EPI_STATS: return launch_ws_one<EPI_ADD | EPI_STATS>(p, stream);
-        case EPI_LN: return launch_ws_one<EPI_LN>(p, stream);
-        case EPI_LN | EPI_ADD: return launch_ws_one<EPI_LN | EPI_ADD>(p, stream);
+        VSX_WS_CASE(0)
+        VSX_WS_CASE(EPI_ADD)
+        VSX_WS_CASE(EPI_STATS)
+        VSX_WS_CASE(EPI_ADD | EPI_STATS)
+        VSX_WS_CASE(EPI_LN)
+        VSX_WS_CASE(EPI_LN | EPI_ADD)
         default: return vsx_fail(VSX_E_UNSUPPORTED, "gemm_ws: no kernel for this epilogue (ws_supported must be asked first)");
     }
+#undef VSX_WS_CASE
 }
 
 }  // namespace vsxg
